@@ -1,0 +1,21 @@
+"""fluid-simulation_amd — MI355X-native stable-fluids grid solver (host-side mirror).
+
+Thin ctypes mirror of the C-ABI in ``include/fluid.h`` (libfluid_hip.so, hand-written
+gfx950 HIP kernels).  The directory name carries a hyphen, so load it with
+``fluid_amd_loader.load()`` (repo root) or ``importlib`` under the module name
+``fluid_simulation_amd``.
+
+There is no CPU fallback: constructing a :class:`FluidSim` without the built HIP
+library or without a GPU raises.  Nothing in this package imports ``oracle/``.
+"""
+from .capi import (FluidLib, FluidSim, FluidError, FluidParams, KernelStat, hip_lib_path,
+                   FIELD_VELOCITY, FIELD_DENSITY, FIELD_PRESSURE, FIELD_DIVERGENCE,
+                   FIELD_VORTICITY, FLAG_VORTICITY, FLAG_NO_GRAPH, FLAG_UNFUSED, ABI_SYMBOLS)
+from .splats import SplatStream, COLOR_PRESETS, alg_bytes_per_cell, run_seeded, DEFAULT_SEED
+
+__all__ = [
+    "FluidLib", "FluidSim", "FluidError", "FluidParams", "KernelStat", "hip_lib_path",
+    "FIELD_VELOCITY", "FIELD_DENSITY", "FIELD_PRESSURE", "FIELD_DIVERGENCE", "FIELD_VORTICITY",
+    "FLAG_VORTICITY", "FLAG_NO_GRAPH", "FLAG_UNFUSED", "ABI_SYMBOLS",
+    "SplatStream", "COLOR_PRESETS", "alg_bytes_per_cell", "run_seeded", "DEFAULT_SEED",
+]

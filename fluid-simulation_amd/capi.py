@@ -1,0 +1,253 @@
+"""ctypes binding of include/fluid.h.
+
+``FluidLib`` binds any shared library that implements the header; ``FluidSim`` is one
+context.  The product path is ``FluidSim(...)`` with the default library
+(csrc/libfluid_hip.so).  Tests bind the CPU oracle through the same class by passing its
+path explicitly — this package never does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+FIELD_VELOCITY, FIELD_DENSITY, FIELD_PRESSURE, FIELD_DIVERGENCE, FIELD_VORTICITY = range(5)
+FLAG_VORTICITY, FLAG_NO_GRAPH, FLAG_UNFUSED = 1, 2, 4
+_FIELD_COMPONENTS = {FIELD_VELOCITY: 2, FIELD_DENSITY: 4, FIELD_PRESSURE: 1, FIELD_DIVERGENCE: 1,
+                     FIELD_VORTICITY: 1}
+
+# Every symbol include/fluid.h declares (checked against the header text in tests).
+ABI_SYMBOLS = [
+    "fluid_default_params", "fluid_init", "fluid_destroy", "fluid_reset", "fluid_add_source",
+    "fluid_step", "fluid_advect_velocity", "fluid_diffuse", "fluid_vorticity", "fluid_project",
+    "fluid_advect_density", "fluid_read", "fluid_write", "fluid_sync", "fluid_geometry",
+    "fluid_strerror", "fluid_last_error", "fluid_time_steps", "fluid_profile_steps",
+    "fluid_stream", "fluid_set_stream",
+]
+
+
+class FluidParams(C.Structure):
+    _fields_ = [
+        ("n", C.c_int), ("diffusion_iters", C.c_int), ("pressure_iters", C.c_int),
+        ("dt", C.c_float), ("viscosity", C.c_float), ("splat_radius", C.c_float),
+        ("device", C.c_int), ("flags", C.c_uint), ("slab_rank", C.c_int), ("slab_count", C.c_int),
+        ("halo_rows", C.c_int), ("reserved", C.c_int * 5),
+    ]
+
+
+class KernelStat(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_int), ("total_ms", C.c_float),
+                ("alg_bytes", C.c_double)]
+
+
+class FluidError(RuntimeError):
+    def __init__(self, code: int, what: str, detail: str = ""):
+        self.code = code
+        super().__init__(f"{what}: error {code}" + (f" ({detail})" if detail else ""))
+
+
+def hip_lib_path() -> str:
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libfluid_hip.so")
+
+
+class FluidLib:
+    """A loaded implementation of include/fluid.h."""
+
+    def __init__(self, path: Optional[str] = None):
+        path = path or hip_lib_path()
+        if not os.path.exists(path):
+            raise FileNotFoundError(
+                f"{path} is not built; run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU fallback)")
+        self.path = path
+        self.dll = C.CDLL(path, mode=C.RTLD_LOCAL)
+        d = self.dll
+        P = C.c_void_p
+
+        def sig(name, res, *args, required=True):
+            try:
+                f = getattr(d, name)
+            except AttributeError:
+                if required:
+                    raise
+                return
+            f.restype, f.argtypes = res, list(args)
+
+        sig("fluid_default_params", C.c_int, C.POINTER(FluidParams))
+        sig("fluid_init", C.c_int, C.POINTER(P), C.POINTER(FluidParams))
+        sig("fluid_destroy", None, P)
+        sig("fluid_reset", C.c_int, P)
+        sig("fluid_add_source", C.c_int, P, C.c_float, C.c_float, C.c_float, C.c_float,
+            C.POINTER(C.c_float))
+        sig("fluid_step", C.c_int, P, C.c_int)
+        for s in ("fluid_advect_velocity", "fluid_diffuse", "fluid_vorticity", "fluid_project",
+                  "fluid_advect_density", "fluid_sync"):
+            sig(s, C.c_int, P)
+        sig("fluid_read", C.c_int, P, C.c_int, P, C.c_size_t)
+        sig("fluid_write", C.c_int, P, C.c_int, P, C.c_size_t)
+        sig("fluid_geometry", C.c_int, P, C.POINTER(C.c_int), C.POINTER(C.c_int),
+            C.POINTER(C.c_int))
+        sig("fluid_strerror", C.c_char_p, C.c_int)
+        sig("fluid_last_error", C.c_char_p, P)
+        # measurement / stream hooks: the oracle does not implement them
+        sig("fluid_time_steps", C.c_int, P, C.c_int, C.POINTER(C.c_float), required=False)
+        sig("fluid_profile_steps", C.c_int, P, C.c_int, C.POINTER(KernelStat), C.c_int,
+            C.POINTER(C.c_int), required=False)
+        sig("fluid_stream", P, P, required=False)
+        sig("fluid_set_stream", C.c_int, P, P, required=False)
+
+    def default_params(self) -> FluidParams:
+        p = FluidParams()
+        rc = self.dll.fluid_default_params(C.byref(p))
+        if rc:
+            raise FluidError(rc, "fluid_default_params")
+        return p
+
+
+_default_lib: Optional[FluidLib] = None
+
+
+def _get_default_lib() -> FluidLib:
+    global _default_lib
+    if _default_lib is None:
+        _default_lib = FluidLib()
+    return _default_lib
+
+
+class FluidSim:
+    """One simulation context.  Mirrors the reference's host functions:
+
+    ===================  =============================================
+    reference            here
+    ===================  =============================================
+    initBuffers()        FluidSim(n=...)              kernel.cu:481-516
+    resetSimulation()    .reset()                     kernel.cu:518-528
+    addForce()           .add_source(sx,sy,fx,fy,rgba) kernel.cu:687-699
+    simulationStep()     .step(k)                     kernel.cu:701-708
+    D2H readback         .read(field)                 kernel.cu:753
+    ===================  =============================================
+    """
+
+    def __init__(self, n: Optional[int] = None, *, diffusion_iters: Optional[int] = None,
+                 pressure_iters: Optional[int] = None, dt: Optional[float] = None,
+                 viscosity: Optional[float] = None, splat_radius: Optional[float] = None,
+                 device: int = 0, flags: int = 0, slab_rank: int = 0, slab_count: int = 0,
+                 halo_rows: int = 0, lib: Optional[FluidLib] = None):
+        self.lib = lib or _get_default_lib()
+        p = self.lib.default_params()
+        if n is not None:
+            p.n = n
+        if diffusion_iters is not None:
+            p.diffusion_iters = diffusion_iters
+        if pressure_iters is not None:
+            p.pressure_iters = pressure_iters
+        if dt is not None:
+            p.dt = dt
+        if viscosity is not None:
+            p.viscosity = viscosity
+        if splat_radius is not None:
+            p.splat_radius = splat_radius
+        p.device, p.flags = device, flags
+        p.slab_rank, p.slab_count, p.halo_rows = slab_rank, slab_count, halo_rows
+        self.params = p
+        self._h = C.c_void_p()
+        rc = self.lib.dll.fluid_init(C.byref(self._h), C.byref(p))
+        if rc:
+            self._h = C.c_void_p()
+            raise FluidError(rc, "fluid_init", self.lib.dll.fluid_strerror(rc).decode())
+        n_, r0, rows = C.c_int(), C.c_int(), C.c_int()
+        self._chk(self.lib.dll.fluid_geometry(self._h, C.byref(n_), C.byref(r0), C.byref(rows)),
+                  "fluid_geometry")
+        self.n, self.row0, self.rows = n_.value, r0.value, rows.value
+
+    # -- plumbing ---------------------------------------------------------------
+    def _chk(self, rc: int, what: str):
+        if rc:
+            detail = self.lib.dll.fluid_strerror(rc).decode()
+            last = self.lib.dll.fluid_last_error(self._h)
+            if last:
+                detail += ": " + last.decode()
+            raise FluidError(rc, what, detail)
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self.lib.dll.fluid_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- the reference's host functions -----------------------------------------
+    def reset(self):
+        self._chk(self.lib.dll.fluid_reset(self._h), "fluid_reset")
+
+    def add_source(self, sx, sy, fx, fy, rgba=(1.0, 1.0, 1.0, 1.0)):
+        col = (C.c_float * 4)(*rgba)
+        self._chk(self.lib.dll.fluid_add_source(self._h, sx, sy, fx, fy, col), "fluid_add_source")
+
+    def step(self, nsteps: int = 1):
+        self._chk(self.lib.dll.fluid_step(self._h, nsteps), "fluid_step")
+
+    def advect_velocity(self):
+        self._chk(self.lib.dll.fluid_advect_velocity(self._h), "fluid_advect_velocity")
+
+    def diffuse(self):
+        self._chk(self.lib.dll.fluid_diffuse(self._h), "fluid_diffuse")
+
+    def vorticity(self):
+        self._chk(self.lib.dll.fluid_vorticity(self._h), "fluid_vorticity")
+
+    def project(self):
+        self._chk(self.lib.dll.fluid_project(self._h), "fluid_project")
+
+    def advect_density(self):
+        self._chk(self.lib.dll.fluid_advect_density(self._h), "fluid_advect_density")
+
+    def sync(self):
+        self._chk(self.lib.dll.fluid_sync(self._h), "fluid_sync")
+
+    def read(self, field: int) -> np.ndarray:
+        comps = _FIELD_COMPONENTS[field]
+        shape = (self.rows, self.n) if comps == 1 else (self.rows, self.n, comps)
+        out = np.empty(shape, dtype=np.float32)
+        self._chk(self.lib.dll.fluid_read(self._h, field, out.ctypes.data_as(C.c_void_p),
+                                          out.nbytes), "fluid_read")
+        return out
+
+    def write(self, field: int, arr: np.ndarray):
+        a = np.ascontiguousarray(arr, dtype=np.float32)
+        self._chk(self.lib.dll.fluid_write(self._h, field, a.ctypes.data_as(C.c_void_p), a.nbytes),
+                  "fluid_write")
+
+    # -- measurement hooks --------------------------------------------------------
+    def time_steps(self, nsteps: int) -> float:
+        ms = C.c_float()
+        self._chk(self.lib.dll.fluid_time_steps(self._h, nsteps, C.byref(ms)), "fluid_time_steps")
+        return ms.value
+
+    def profile_steps(self, nsteps: int):
+        stats = (KernelStat * 16)()
+        cnt = C.c_int()
+        self._chk(self.lib.dll.fluid_profile_steps(self._h, nsteps, stats, 16, C.byref(cnt)),
+                  "fluid_profile_steps")
+        return [dict(name=stats[i].name.decode(), launches=stats[i].launches,
+                     total_ms=stats[i].total_ms, alg_bytes=stats[i].alg_bytes)
+                for i in range(cnt.value)]
+
+    def stream(self) -> int:
+        return self.lib.dll.fluid_stream(self._h) or 0
+
+    def set_stream(self, hip_stream: int):
+        self._chk(self.lib.dll.fluid_set_stream(self._h, C.c_void_p(hip_stream)),
+                  "fluid_set_stream")

@@ -1,0 +1,506 @@
+// fluid_api.hip — host side of libfluid_hip.so: the C-ABI of include/fluid.h.
+//
+// Replaces the reference's L2 host layer (/root/reference/FluidSimulation/
+// kernel.cu:435-708): buffer allocation, ping-pong indices, stage ordering and
+// iteration counts.  The reference's ~99 texture/surface bind calls and 25
+// null-stream launches per step become one hipGraph replay on the context's
+// stream.  Product code: no CPU fallback, nothing from oracle/.
+#include "fluid_internal.h"
+#include "../../include/fluid.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <new>
+#include <vector>
+
+namespace {
+
+struct GraphEntry {
+  hipGraphExec_t exec = nullptr;
+  hipGraph_t graph = nullptr;
+  int next_state = 0;
+};
+
+struct ProfRec {
+  int kid;
+  int e0, e1;
+  double bytes;
+};
+
+}  // namespace
+
+struct fluid_ctx {
+  fluid_params prm;
+  Geom g;
+  int row0 = 0, rows = 0;  // owned global rows [row0, row0 + rows)
+  int own_r0 = 0;          // local row of the first owned row
+  float2 *vel[2] = {nullptr, nullptr};   // velocityBufferArray[2]  kernel.cu:443-444
+  float4 *dens[2] = {nullptr, nullptr};  // densityBufferArray[2]   kernel.cu:447-448
+  float *prs[2] = {nullptr, nullptr};    // pressureBufferArray[2]  kernel.cu:452-453
+  float *div = nullptr;                  // kernel.cu:455-456
+  float *vort = nullptr;                 // kernel.cu:458-459 (allocated on first use)
+  int vin = 0, din = 0, pin = 0;  // inputVelocityBuffer / inputDensityBuffer / inputPressureBuffer
+  int *halo_flag = nullptr;       // device word: advection left the stored rows
+  float alpha = 0.f, beta = 0.f;  // diffusion constants, kernel.cu:182-183
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  std::map<int, GraphEntry> graphs;
+  bool prof = false;
+  std::vector<hipEvent_t> ev_pool;
+  size_t ev_used = 0;
+  std::vector<ProfRec> recs;
+  char err[256] = {0};
+};
+
+namespace {
+
+int fail(fluid_ctx *c, int code, const char *fmt, ...) {
+  if (c) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(c->err, sizeof c->err, fmt, ap);
+    va_end(ap);
+  }
+  return code;
+}
+
+#define HIPCHK(c, call)                                                                  \
+  do {                                                                                   \
+    hipError_t e_ = (call);                                                              \
+    if (e_ != hipSuccess)                                                                \
+      return fail((c), e_ == hipErrorOutOfMemory ? FLUID_E_NOMEM : FLUID_E_DEVICE,       \
+                  "%s: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__);   \
+  } while (0)
+
+inline size_t cells_local(const fluid_ctx *c) { return (size_t)c->g.L * c->g.n; }
+inline size_t cells_owned(const fluid_ctx *c) { return (size_t)c->rows * c->g.n; }
+inline int state_of(const fluid_ctx *c) { return c->vin | (c->din << 1) | (c->pin << 2); }
+inline void set_state(fluid_ctx *c, int s) { c->vin = s & 1; c->din = (s >> 1) & 1; c->pin = (s >> 2) & 1; }
+
+void drop_graphs(fluid_ctx *c) {
+  for (auto &kv : c->graphs) {
+    if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+    if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
+  }
+  c->graphs.clear();
+}
+
+// ---- per-launch profiling (fluid_profile_steps) -----------------------------
+int prof_event(fluid_ctx *c) {
+  if (c->ev_used == c->ev_pool.size()) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return -1;
+    c->ev_pool.push_back(e);
+  }
+  return (int)c->ev_used++;
+}
+struct ProfScope {
+  fluid_ctx *c;
+  int kid, e0 = -1;
+  double bytes;
+  ProfScope(fluid_ctx *c_, int kid_, double bytes_) : c(c_), kid(kid_), bytes(bytes_) {
+    if (c->prof) {
+      e0 = prof_event(c);
+      if (e0 >= 0) (void)hipEventRecord(c->ev_pool[e0], c->stream);
+    }
+  }
+  ~ProfScope() {
+    if (c->prof && e0 >= 0) {
+      int e1 = prof_event(c);
+      if (e1 >= 0) {
+        (void)hipEventRecord(c->ev_pool[e1], c->stream);
+        c->recs.push_back({kid, e0, e1, bytes});
+      }
+    }
+  }
+};
+
+// ---- stage enqueue: the reference's host stage functions --------------------
+// Row ranges are local rows; for a whole-domain context [0, n).
+
+// simulateAdvection()  kernel.cu:542-555
+void enq_advect_velocity(fluid_ctx *c) {
+  const double cells = (double)cells_owned(c);
+  ProfScope p(c, K_ADVECT_VEL, 16.0 * cells);
+  launch_advect_vel(c->stream, c->g, c->own_r0, c->own_r0 + c->rows, c->prm.dt, c->vel[c->vin],
+                    c->vel[c->vin ^ 1], c->halo_flag);
+  c->vin ^= 1;
+}
+
+// simulateDiffusion()  kernel.cu:582-602
+void enq_diffuse(fluid_ctx *c) {
+  const double cells = (double)cells_owned(c);
+  for (int i = 0; i < c->prm.diffusion_iters; ++i) {
+    ProfScope p(c, K_DIFFUSE, 16.0 * cells);
+    launch_diffuse(c->stream, c->g, c->own_r0, c->own_r0 + c->rows, c->alpha, c->beta,
+                   c->vel[c->vin], c->vel[c->vin ^ 1]);
+    c->vin ^= 1;
+  }
+}
+
+// simulateVorticity()  kernel.cu:557-580
+void enq_vorticity(fluid_ctx *c) {
+  const double cells = (double)cells_owned(c);
+  {
+    ProfScope p(c, K_VORTICITY, 12.0 * cells);
+    launch_vorticity(c->stream, c->g, c->own_r0, c->own_r0 + c->rows, c->vel[c->vin], c->vort);
+  }
+  {
+    ProfScope p(c, K_ADD_VORTICITY, 20.0 * cells);
+    launch_add_vorticity(c->stream, c->g, c->own_r0, c->own_r0 + c->rows, c->prm.dt, c->vort,
+                         c->vel[c->vin]);
+  }
+}
+
+// projection()  kernel.cu:604-662
+void enq_project(fluid_ctx *c) {
+  const double cells = (double)cells_owned(c);
+  const int r0 = c->own_r0, r1 = c->own_r0 + c->rows;
+  {
+    ProfScope p(c, K_DIVERGENCE, 12.0 * cells);
+    launch_divergence(c->stream, c->g, r0, r1, c->vel[c->vin], c->div);
+  }
+  // resetPressure()  kernel.cu:530-540: only the pressure clear is live (the
+  // other two targets are overwritten before they are read).
+  (void)hipMemsetAsync(c->prs[c->pin], 0, cells_local(c) * sizeof(float), c->stream);
+  for (int i = 0; i < c->prm.pressure_iters; ++i) {
+    ProfScope p(c, K_JACOBI, 12.0 * cells);
+    launch_jacobi(c->stream, c->g, r0, r1, c->prs[c->pin], c->div, c->prs[c->pin ^ 1]);
+    c->pin ^= 1;
+  }
+  {
+    ProfScope p(c, K_PROJECT, 20.0 * cells);
+    launch_project(c->stream, c->g, r0, r1, c->vel[c->vin], c->prs[c->pin], c->vel[c->vin ^ 1]);
+    c->vin ^= 1;
+  }
+}
+
+// simulateDensityAdvection()  kernel.cu:664-685
+void enq_advect_density(fluid_ctx *c) {
+  const double cells = (double)cells_owned(c);
+  ProfScope p(c, K_ADVECT_DENS, 40.0 * cells);
+  launch_advect_dens(c->stream, c->g, c->own_r0, c->own_r0 + c->rows, c->prm.dt, c->vel[c->vin],
+                     c->dens[c->din], c->dens[c->din ^ 1], c->halo_flag);
+  c->din ^= 1;
+}
+
+// simulationStep()  kernel.cu:701-708
+void enq_step(fluid_ctx *c) {
+  enq_advect_velocity(c);
+  enq_diffuse(c);
+  if (c->prm.flags & FLUID_FLAG_VORTICITY) enq_vorticity(c);  // kernel.cu:705
+  enq_project(c);
+  enq_advect_density(c);
+}
+
+int check_launch(fluid_ctx *c) {
+  hipError_t e = hipGetLastError();  // cudaPeekAtLastError after every launch, e.g. kernel.cu:552
+  if (e != hipSuccess) return fail(c, FLUID_E_DEVICE, "kernel launch: %s", hipGetErrorString(e));
+  return FLUID_OK;
+}
+
+int run_steps(fluid_ctx *c, int nsteps) {
+  const bool direct = (c->prm.flags & FLUID_FLAG_NO_GRAPH) || c->prof;
+  for (int s = 0; s < nsteps; ++s) {
+    if (direct) {
+      enq_step(c);
+      int rc = check_launch(c);
+      if (rc) return rc;
+      continue;
+    }
+    const int key = state_of(c);
+    auto it = c->graphs.find(key);
+    if (it == c->graphs.end()) {
+      GraphEntry ge;
+      HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+      enq_step(c);
+      hipError_t e = hipStreamEndCapture(c->stream, &ge.graph);
+      ge.next_state = state_of(c);
+      set_state(c, key);
+      if (e != hipSuccess) return fail(c, FLUID_E_DEVICE, "hipStreamEndCapture: %s", hipGetErrorString(e));
+      HIPCHK(c, hipGraphInstantiate(&ge.exec, ge.graph, nullptr, nullptr, 0));
+      it = c->graphs.emplace(key, ge).first;
+    }
+    HIPCHK(c, hipGraphLaunch(it->second.exec, c->stream));
+    set_state(c, it->second.next_state);
+  }
+  return FLUID_OK;
+}
+
+int ensure_vort(fluid_ctx *c) {
+  if (!c->vort) {
+    HIPCHK(c, hipMalloc(&c->vort, cells_local(c) * sizeof(float)));
+    HIPCHK(c, hipMemsetAsync(c->vort, 0, cells_local(c) * sizeof(float), c->stream));
+  }
+  return FLUID_OK;
+}
+
+void *field_ptr(fluid_ctx *c, int field, size_t *elem) {
+  switch (field) {
+    case FLUID_VELOCITY: *elem = sizeof(float2); return c->vel[c->vin];
+    case FLUID_DENSITY: *elem = sizeof(float4); return c->dens[c->din];
+    case FLUID_PRESSURE: *elem = sizeof(float); return c->prs[c->pin];
+    case FLUID_DIVERGENCE: *elem = sizeof(float); return c->div;
+    case FLUID_VORTICITY: *elem = sizeof(float); return c->vort;
+  }
+  return nullptr;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fluid_default_params(fluid_params *p) {
+  if (!p) return FLUID_E_INVALID;
+  memset(p, 0, sizeof *p);
+  p->n = 512;               // kernel.cu:438
+  p->diffusion_iters = 10;  // kernel.cu:584
+  p->pressure_iters = 10;   // kernel.cu:620
+  p->dt = 0.1f;             // kernel.cu:31
+  p->viscosity = 0.01f;     // kernel.cu:181
+  p->splat_radius = 0.001f; // kernel.cu:368
+  return FLUID_OK;
+}
+
+int fluid_init(fluid_ctx **out, const fluid_params *p) {
+  if (!out) return FLUID_E_INVALID;
+  *out = nullptr;
+  fluid_params prm;
+  if (p) prm = *p; else fluid_default_params(&prm);
+  if (prm.n < 4 || prm.diffusion_iters < 0 || prm.pressure_iters < 0) return FLUID_E_INVALID;
+  if (prm.slab_count > 1) return FLUID_E_UNSUPPORTED;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return FLUID_E_DEVICE;  // no CPU fallback
+  if (prm.device < 0 || prm.device >= ndev) return FLUID_E_INVALID;
+  fluid_ctx *c = new (std::nothrow) fluid_ctx();
+  if (!c) return FLUID_E_NOMEM;
+  c->prm = prm;
+  c->g = Geom{prm.n, 0, prm.n};
+  c->row0 = 0;
+  c->rows = prm.n;
+  c->own_r0 = 0;
+  c->alpha = 1.0f / (prm.viscosity * prm.dt);  // kernel.cu:182, fp32 at run time
+  c->beta = 1.0f / (4.0f + c->alpha);          // kernel.cu:183
+  int rc = [&]() -> int {
+    HIPCHK(c, hipSetDevice(prm.device));
+    HIPCHK(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    const size_t nc = cells_local(c);
+    for (int i = 0; i < 2; ++i) {
+      HIPCHK(c, hipMalloc(&c->vel[i], nc * sizeof(float2)));
+      HIPCHK(c, hipMalloc(&c->dens[i], nc * sizeof(float4)));
+      HIPCHK(c, hipMalloc(&c->prs[i], nc * sizeof(float)));
+      // The reference zeroes only the current halves (kernel.cu:518-528); the
+      // others are fully overwritten before first read.  Zero all: it is free.
+      HIPCHK(c, hipMemsetAsync(c->vel[i], 0, nc * sizeof(float2), c->stream));
+      HIPCHK(c, hipMemsetAsync(c->dens[i], 0, nc * sizeof(float4), c->stream));
+      HIPCHK(c, hipMemsetAsync(c->prs[i], 0, nc * sizeof(float), c->stream));
+    }
+    HIPCHK(c, hipMalloc(&c->div, nc * sizeof(float)));
+    HIPCHK(c, hipMemsetAsync(c->div, 0, nc * sizeof(float), c->stream));
+    HIPCHK(c, hipMalloc(&c->halo_flag, 256));
+    HIPCHK(c, hipMemsetAsync(c->halo_flag, 0, 256, c->stream));
+    if (prm.flags & FLUID_FLAG_VORTICITY) {
+      int r = ensure_vort(c);
+      if (r) return r;
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return FLUID_OK;
+  }();
+  if (rc != FLUID_OK) {
+    fluid_destroy(c);
+    return rc;
+  }
+  *out = c;
+  return FLUID_OK;
+}
+
+void fluid_destroy(fluid_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->prm.device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  drop_graphs(c);
+  for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+  for (int i = 0; i < 2; ++i) {
+    if (c->vel[i]) (void)hipFree(c->vel[i]);
+    if (c->dens[i]) (void)hipFree(c->dens[i]);
+    if (c->prs[i]) (void)hipFree(c->prs[i]);
+  }
+  if (c->div) (void)hipFree(c->div);
+  if (c->vort) (void)hipFree(c->vort);
+  if (c->halo_flag) (void)hipFree(c->halo_flag);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+int fluid_reset(fluid_ctx *c) {
+  if (!c) return FLUID_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->prm.device));
+  const size_t nc = cells_local(c);
+  HIPCHK(c, hipMemsetAsync(c->vel[c->vin], 0, nc * sizeof(float2), c->stream));
+  HIPCHK(c, hipMemsetAsync(c->prs[c->pin], 0, nc * sizeof(float), c->stream));
+  HIPCHK(c, hipMemsetAsync(c->dens[c->din], 0, nc * sizeof(float4), c->stream));
+  return FLUID_OK;
+}
+
+int fluid_add_source(fluid_ctx *c, float sx, float sy, float fx, float fy, const float rgba[4]) {
+  if (!c || !rgba) return FLUID_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->prm.device));
+  ProfScope p(c, K_ADD_FORCE, 48.0 * (double)cells_owned(c));
+  launch_add_force(c->stream, c->g, c->own_r0, c->own_r0 + c->rows, c->prm.dt, c->prm.splat_radius,
+                   sx, sy, fx, fy, make_float4(rgba[0], rgba[1], rgba[2], rgba[3]), c->vel[c->vin],
+                   c->dens[c->din]);
+  return check_launch(c);
+}
+
+int fluid_step(fluid_ctx *c, int nsteps) {
+  if (!c || nsteps < 0) return FLUID_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->prm.device));
+  return run_steps(c, nsteps);
+}
+
+#define STAGE_FN(name, enq, pre)                \
+  int name(fluid_ctx *c) {                      \
+    if (!c) return FLUID_E_INVALID;             \
+    HIPCHK(c, hipSetDevice(c->prm.device));     \
+    pre;                                        \
+    enq(c);                                     \
+    return check_launch(c);                     \
+  }
+STAGE_FN(fluid_advect_velocity, enq_advect_velocity, (void)0)
+STAGE_FN(fluid_diffuse, enq_diffuse, (void)0)
+STAGE_FN(fluid_vorticity, enq_vorticity, { int r_ = ensure_vort(c); if (r_) return r_; })
+STAGE_FN(fluid_project, enq_project, (void)0)
+STAGE_FN(fluid_advect_density, enq_advect_density, (void)0)
+
+int fluid_read(fluid_ctx *c, int field, void *dst, size_t dst_bytes) {
+  if (!c || !dst) return FLUID_E_INVALID;
+  size_t elem = 0;
+  char *src = (char *)field_ptr(c, field, &elem);
+  if (!elem) return FLUID_E_INVALID;
+  const size_t bytes = cells_owned(c) * elem;
+  if (dst_bytes < bytes) return FLUID_E_SIZE;
+  HIPCHK(c, hipSetDevice(c->prm.device));
+  if (!src) {  // vorticity never computed: reads as zeros
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    memset(dst, 0, bytes);
+    return FLUID_OK;
+  }
+  src += (size_t)c->own_r0 * c->g.n * elem;
+  HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return FLUID_OK;
+}
+
+int fluid_write(fluid_ctx *c, int field, const void *srcv, size_t src_bytes) {
+  if (!c || !srcv) return FLUID_E_INVALID;
+  if (field == FLUID_VORTICITY) {
+    int r = ensure_vort(c);
+    if (r) return r;
+  }
+  size_t elem = 0;
+  char *dst = (char *)field_ptr(c, field, &elem);
+  if (!dst) return FLUID_E_INVALID;
+  const size_t bytes = cells_owned(c) * elem;
+  if (src_bytes != bytes) return FLUID_E_SIZE;
+  HIPCHK(c, hipSetDevice(c->prm.device));
+  dst += (size_t)c->own_r0 * c->g.n * elem;
+  HIPCHK(c, hipMemcpyAsync(dst, srcv, bytes, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return FLUID_OK;
+}
+
+int fluid_sync(fluid_ctx *c) {
+  if (!c) return FLUID_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->prm.device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return FLUID_OK;
+}
+
+int fluid_geometry(const fluid_ctx *c, int *n, int *row0, int *rows) {
+  if (!c) return FLUID_E_INVALID;
+  if (n) *n = c->g.n;
+  if (row0) *row0 = c->row0;
+  if (rows) *rows = c->rows;
+  return FLUID_OK;
+}
+
+const char *fluid_strerror(int code) {
+  switch (code) {
+    case FLUID_OK: return "ok";
+    case FLUID_E_INVALID: return "invalid argument";
+    case FLUID_E_NOMEM: return "out of memory";
+    case FLUID_E_DEVICE: return "device error";
+    case FLUID_E_SIZE: return "buffer size mismatch";
+    case FLUID_E_COMM: return "halo transport error";
+    case FLUID_E_HALO: return "advection left the slab halo";
+    case FLUID_E_UNSUPPORTED: return "unsupported";
+  }
+  return "unknown error";
+}
+
+const char *fluid_last_error(const fluid_ctx *c) { return c ? c->err : ""; }
+
+int fluid_time_steps(fluid_ctx *c, int nsteps, float *ms_out) {
+  if (!c || nsteps < 0 || !ms_out) return FLUID_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->prm.device));
+  hipEvent_t e0, e1;
+  HIPCHK(c, hipEventCreate(&e0));
+  HIPCHK(c, hipEventCreate(&e1));
+  int rc = [&]() -> int {
+    HIPCHK(c, hipEventRecord(e0, c->stream));
+    int r = run_steps(c, nsteps);
+    if (r) return r;
+    HIPCHK(c, hipEventRecord(e1, c->stream));
+    HIPCHK(c, hipEventSynchronize(e1));
+    HIPCHK(c, hipEventElapsedTime(ms_out, e0, e1));
+    return FLUID_OK;
+  }();
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return rc;
+}
+
+int fluid_profile_steps(fluid_ctx *c, int nsteps, fluid_kernel_stat *stats, int max_stats,
+                        int *count) {
+  if (!c || nsteps < 0 || !stats || !count || max_stats <= 0) return FLUID_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->prm.device));
+  c->prof = true;
+  c->ev_used = 0;
+  c->recs.clear();
+  int rc = run_steps(c, nsteps);
+  c->prof = false;
+  if (rc) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  fluid_kernel_stat acc[K_COUNT];
+  memset(acc, 0, sizeof acc);
+  for (const ProfRec &r : c->recs) {
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev_pool[r.e0], c->ev_pool[r.e1]));
+    acc[r.kid].launches += 1;
+    acc[r.kid].total_ms += ms;
+    acc[r.kid].alg_bytes = r.bytes;
+  }
+  int k = 0;
+  for (int i = 0; i < K_COUNT && k < max_stats; ++i) {
+    if (!acc[i].launches) continue;
+    snprintf(acc[i].name, sizeof acc[i].name, "%s", kKernelNames[i]);
+    stats[k++] = acc[i];
+  }
+  *count = k;
+  return FLUID_OK;
+}
+
+void *fluid_stream(fluid_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+int fluid_set_stream(fluid_ctx *c, void *hip_stream) {
+  if (!c) return FLUID_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->prm.device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  drop_graphs(c);
+  c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+  return FLUID_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,51 @@
+// fluid_internal.h — shared between the kernel TU and the C-ABI host TU.
+// Product code (gfx950 only).  Nothing here touches oracle/.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+// Geometry of one context's local buffers.  The domain is n x n; the context
+// stores rows [ybase, ybase + L) (its owned rows plus halo rows); local row r
+// is global row ybase + r.  Whole-domain contexts have ybase = 0, L = n.
+struct Geom {
+  int n;      // global grid edge (cells)
+  int ybase;  // global y of local row 0
+  int L;      // local rows stored
+};
+
+// Kernel ids for per-kernel timing (fluid_profile_steps) and rocprof matching.
+enum KernelId {
+  K_ADVECT_VEL = 0,
+  K_DIFFUSE,
+  K_DIVERGENCE,
+  K_JACOBI,
+  K_PROJECT,
+  K_ADVECT_DENS,
+  K_ADD_FORCE,
+  K_VORTICITY,
+  K_ADD_VORTICITY,
+  K_DIFFUSE_TB,   // temporally blocked diffusion
+  K_JACOBI_TB,    // temporally blocked Jacobi (optionally fused divergence prologue)
+  K_COUNT
+};
+extern const char *const kKernelNames[K_COUNT];
+
+// ---- straight (one launch per reference launch) kernels ---------------------
+// All take local row range [r0, r1) to compute; reads reach one row beyond
+// (stencils) or up to the advection halo (gathers).
+void launch_advect_vel(hipStream_t s, Geom g, int r0, int r1, float dt, const float2 *vin,
+                       float2 *vout, int *halo_flag);
+void launch_diffuse(hipStream_t s, Geom g, int r0, int r1, float alpha, float beta,
+                    const float2 *vin, float2 *vout);
+void launch_divergence(hipStream_t s, Geom g, int r0, int r1, const float2 *vel, float *div);
+void launch_jacobi(hipStream_t s, Geom g, int r0, int r1, const float *pin, const float *div,
+                   float *pout);
+void launch_project(hipStream_t s, Geom g, int r0, int r1, const float2 *vin, const float *p,
+                    float2 *vout);
+void launch_advect_dens(hipStream_t s, Geom g, int r0, int r1, float dt, const float2 *vel,
+                        const float4 *din, float4 *dout, int *halo_flag);
+void launch_add_force(hipStream_t s, Geom g, int r0, int r1, float dt, float radius, float sx,
+                      float sy, float fx, float fy, float4 rgba, float2 *vel, float4 *dens);
+void launch_vorticity(hipStream_t s, Geom g, int r0, int r1, const float2 *vel, float *vort);
+void launch_add_vorticity(hipStream_t s, Geom g, int r0, int r1, float dt, const float *vort,
+                          float2 *vel);

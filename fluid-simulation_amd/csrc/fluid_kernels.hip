@@ -1,0 +1,287 @@
+// fluid_kernels.hip — straight gfx950 kernels: one launch per launch of the
+// reference's simulationStep() (/root/reference/FluidSimulation/kernel.cu:701-708).
+//
+// These are the parity baseline (FLUID_FLAG_UNFUSED) and the building blocks
+// the temporally blocked kernels in fluid_kernels_tb.hip are checked against.
+// Written for wave64: blocks are 64 lanes wide in x so every wave reads and
+// writes whole contiguous row segments (float2: 512 B, float4: 1 KiB per wave
+// instruction), four rows per block.
+//
+// Arithmetic contract: fp32 only, no FMA contraction, the
+// reference's written summation order, bilinear in the author's mix() form
+// x + (y - x) * a (kernel.cu:60-71), texture clamp-to-edge restated as index
+// clamps.  With that contract every kernel here is bit-identical to the CPU
+// oracle on the same input; only expf (add_force) may differ in the last ulp.
+#include "fluid_internal.h"
+
+#pragma clang fp contract(off)
+
+const char *const kKernelNames[K_COUNT] = {
+    "k_advect_vel", "k_diffuse",   "k_divergence",    "k_jacobi",     "k_project", "k_advect_dens",
+    "k_add_force",  "k_vorticity", "k_add_vorticity", "k_diffuse_tb", "k_jacobi_tb"};
+
+namespace {
+
+constexpr int BX = 64;  // one wave wide
+constexpr int BY = 4;
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
+__device__ __forceinline__ float2 neg(float2 v) { return make_float2(-v.x, -v.y); }
+// kernel.cu:60-71
+__device__ __forceinline__ float mixf(float x, float y, float a) { return x + (y - x) * a; }
+__device__ __forceinline__ float2 mix(float2 x, float2 y, float a) {
+  return make_float2(mixf(x.x, y.x, a), mixf(x.y, y.y, a));
+}
+__device__ __forceinline__ float4 mix(float4 x, float4 y, float a) {
+  return make_float4(mixf(x.x, y.x, a), mixf(x.y, y.y, a), mixf(x.z, y.z, a), mixf(x.w, y.w, a));
+}
+
+// Clamp-to-edge texel fetch in GLOBAL coordinates from a local (slab) buffer.
+// A row outside the stored rows raises *flag (advection left the halo) and is
+// clamped so the access stays in bounds.
+template <typename T>
+__device__ __forceinline__ T texel(const T *t, Geom g, int i, int j, int *flag) {
+  i = clampi(i, 0, g.n - 1);
+  int r = clampi(j, 0, g.n - 1) - g.ybase;
+  if (r < 0 || r >= g.L) {
+    if (flag) *flag = 1;
+    r = clampi(r, 0, g.L - 1);
+  }
+  return t[(size_t)r * g.n + i];
+}
+
+// LINEAR fetch at texture coordinate (bx + .5, by + .5): SURVEY.md Appendix B.2.
+template <typename T>
+__device__ __forceinline__ T bilinear(const T *t, Geom g, float bx, float by, int *flag) {
+  float fi = floorf(bx), fj = floorf(by);
+  float a = bx - fi, b = by - fj;
+  int i = (int)fi, j = (int)fj;
+  T v0 = mix(texel(t, g, i, j, flag), texel(t, g, i + 1, j, flag), a);
+  T v1 = mix(texel(t, g, i, j + 1, flag), texel(t, g, i + 1, j + 1, flag), a);
+  return mix(v0, v1, b);
+}
+// LINEAR fetch at INTEGER texture coordinates: Appendix B.3 (2x2 mean).
+__device__ __forceinline__ float2 linear_at_int(const float2 *t, Geom g, int m, int k) {
+  float2 v0 = mix(texel(t, g, m - 1, k - 1, nullptr), texel(t, g, m, k - 1, nullptr), 0.5f);
+  float2 v1 = mix(texel(t, g, m - 1, k, nullptr), texel(t, g, m, k, nullptr), 0.5f);
+  return mix(v0, v1, 0.5f);
+}
+
+#define CELL_PROLOGUE                                     \
+  const int x = blockIdx.x * BX + threadIdx.x;            \
+  const int r = r0 + blockIdx.y * BY + threadIdx.y;       \
+  if (x >= g.n || r >= r1) return;                        \
+  const int y = g.ybase + r;                              \
+  const size_t id = (size_t)r * g.n + x;                  \
+  const bool interior = x > 0 && x < g.n - 1 && y > 0 && y < g.n - 1;
+
+// kernel.cu:114-140
+__global__ __launch_bounds__(BX *BY) void k_advect_vel(Geom g, int r0, int r1, float dt,
+                                                        const float2 *__restrict__ vin,
+                                                        float2 *__restrict__ vout, int *flag) {
+  CELL_PROLOGUE
+  if (interior) {
+    float2 v = vin[id];
+    float px = (float)x - dt * v.x;
+    float py = (float)y - dt * v.y;
+    px = fmaxf(0.0f, fminf(px, (float)g.n));
+    py = fmaxf(0.0f, fminf(py, (float)g.n));
+    vout[id] = bilinear(vin, g, px, py, flag);
+  } else {
+    float2 o = make_float2(0.0f, 0.0f);
+    if (x == 0) o = neg(linear_at_int(vin, g, x + 1, y));
+    if (x == g.n - 1) o = neg(linear_at_int(vin, g, x - 1, y));
+    if (y == 0) o = neg(linear_at_int(vin, g, x + 1, y + 1));
+    if (y == g.n - 1) o = neg(linear_at_int(vin, g, x + 1, y - 1));
+    vout[id] = o;
+  }
+}
+
+// kernel.cu:142-165
+__global__ __launch_bounds__(BX *BY) void k_advect_dens(Geom g, int r0, int r1, float dt,
+                                                         const float2 *__restrict__ vel,
+                                                         const float4 *__restrict__ din,
+                                                         float4 *__restrict__ dout, int *flag) {
+  CELL_PROLOGUE
+  if (interior) {
+    float2 v = vel[id];
+    float px = (float)x - dt * v.x;
+    float py = (float)y - dt * v.y;
+    px = fmaxf(0.0f, fminf(px, (float)g.n));
+    py = fmaxf(0.0f, fminf(py, (float)g.n));
+    dout[id] = bilinear(din, g, px, py, flag);
+  } else {
+    dout[id] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  }
+}
+
+// kernel.cu:173-205 (one sweep)
+__global__ __launch_bounds__(BX *BY) void k_diffuse(Geom g, int r0, int r1, float alpha, float beta,
+                                                     const float2 *__restrict__ vin,
+                                                     float2 *__restrict__ vout) {
+  CELL_PROLOGUE
+  float2 v = vin[id];
+  if (interior) {
+    float2 vL = vin[id - 1], vR = vin[id + 1], vB = vin[id - g.n], vT = vin[id + g.n];
+    float2 o;
+    o.x = ((((vL.x + vR.x) + vB.x) + vT.x) + alpha * v.x) * beta;
+    o.y = ((((vL.y + vR.y) + vB.y) + vT.y) + alpha * v.y) * beta;
+    vout[id] = o;
+  } else {
+    vout[id] = v;
+  }
+}
+
+// kernel.cu:265-289
+__global__ __launch_bounds__(BX *BY) void k_divergence(Geom g, int r0, int r1,
+                                                        const float2 *__restrict__ vel,
+                                                        float *__restrict__ div) {
+  CELL_PROLOGUE
+  if (interior) {
+    float2 vL = vel[id - 1], vR = vel[id + 1], vB = vel[id - g.n], vT = vel[id + g.n];
+    div[id] = 0.5f * ((vR.x - vL.x) + (vT.y - vB.y));
+  } else {
+    div[id] = 0.0f;
+  }
+}
+
+// kernel.cu:291-324 (one sweep)
+__global__ __launch_bounds__(BX *BY) void k_jacobi(Geom g, int r0, int r1,
+                                                    const float *__restrict__ pin,
+                                                    const float *__restrict__ div,
+                                                    float *__restrict__ pout) {
+  CELL_PROLOGUE
+  if (interior) {
+    float vL = pin[id - 1], vR = pin[id + 1], vB = pin[id - g.n], vT = pin[id + g.n];
+    float d = div[id];
+    pout[id] = ((((vL + vR) + vB) + vT) + (-1.0f) * d) * 0.25f;
+  } else {
+    float o = 0.0f;
+    if (x == 0) o = -pin[id + 1];
+    if (x == g.n - 1) o = -pin[id - 1];
+    if (y == 0) o = -pin[id + g.n];
+    if (y == g.n - 1) o = -pin[id - g.n];
+    pout[id] = o;
+  }
+}
+
+// kernel.cu:326-355
+__global__ __launch_bounds__(BX *BY) void k_project(Geom g, int r0, int r1,
+                                                     const float2 *__restrict__ vin,
+                                                     const float *__restrict__ p,
+                                                     float2 *__restrict__ vout) {
+  CELL_PROLOGUE
+  if (interior) {
+    float pL = p[id - 1], pR = p[id + 1], pB = p[id - g.n], pT = p[id + g.n];
+    float2 v = vin[id];
+    vout[id] = make_float2(v.x - (pR - pL), v.y - (pT - pB));
+  } else {
+    float2 o = make_float2(0.0f, 0.0f);
+    const int xp = min(x + 1, g.n - 1);  // clamp-to-edge of x+1 (kernel.cu:352-353)
+    if (x == 0) o = neg(vin[id + 1]);
+    if (x == g.n - 1) o = neg(vin[id - 1]);
+    if (y == 0) o = neg(vin[(size_t)(r + 1) * g.n + xp]);
+    if (y == g.n - 1) o = neg(vin[(size_t)(r - 1) * g.n + xp]);
+    vout[id] = o;
+  }
+}
+
+// kernel.cu:357-383 (every cell, border included)
+__global__ __launch_bounds__(BX *BY) void k_add_force(Geom g, int r0, int r1, float dt, float radius,
+                                                       float sx, float sy, float fx, float fy,
+                                                       float4 rgba, float2 *__restrict__ vel,
+                                                       float4 *__restrict__ dens) {
+  CELL_PROLOGUE
+  (void)interior;
+  float dx = ((float)x / (float)g.n) - sx;
+  float dy = ((float)y / (float)g.n) - sy;
+  float c = expf(-(dx * dx + dy * dy) / radius) * dt;
+  float2 v = vel[id];
+  vel[id] = make_float2(v.x + c * fx, v.y + c * fy);
+  float4 d = dens[id];
+  dens[id] = make_float4(d.x + c * rgba.x, d.y + c * rgba.y, d.z + c * rgba.z, d.w + c * rgba.w);
+}
+
+// kernel.cu:207-230
+__global__ __launch_bounds__(BX *BY) void k_vorticity(Geom g, int r0, int r1,
+                                                       const float2 *__restrict__ vel,
+                                                       float *__restrict__ vort) {
+  CELL_PROLOGUE
+  if (interior) {
+    float2 vL = vel[id - 1], vR = vel[id + 1], vB = vel[id - g.n], vT = vel[id + g.n];
+    vort[id] = (vR.y - vL.y) - (vT.x - vB.x);
+  } else {
+    vort[id] = 0.0f;
+  }
+}
+
+// kernel.cu:232-263
+__global__ __launch_bounds__(BX *BY) void k_add_vorticity(Geom g, int r0, int r1, float dt,
+                                                           const float *__restrict__ vort,
+                                                           float2 *__restrict__ vel) {
+  CELL_PROLOGUE
+  if (!interior) return;
+  float vL = vort[id - 1], vR = vort[id + 1], vB = vort[id - g.n], vT = vort[id + g.n];
+  float gx = vR - vL, gy = vT - vB;
+  float d = ((gx * gx + gy * gy) + 0.0f * 0.0f) + 0.0f * 0.0f;
+  if (d) {
+    float cx = gy * 1.0f - 0.0f * 0.0f;
+    float cy = 0.0f * 0.0f - gx * 1.0f;
+    float fx = 0.2f * cx, fy = 0.2f * cy;
+    float2 v = vel[id];
+    vel[id] = make_float2(v.x + fx * dt, v.y + fy * dt);
+  }
+}
+
+inline dim3 grid_for(Geom g, int r0, int r1) {
+  return dim3((g.n + BX - 1) / BX, (r1 - r0 + BY - 1) / BY);
+}
+const dim3 kBlock(BX, BY);
+
+}  // namespace
+
+void launch_advect_vel(hipStream_t s, Geom g, int r0, int r1, float dt, const float2 *vin,
+                       float2 *vout, int *flag) {
+  if (r1 <= r0) return;
+  hipLaunchKernelGGL(k_advect_vel, grid_for(g, r0, r1), kBlock, 0, s, g, r0, r1, dt, vin, vout, flag);
+}
+void launch_diffuse(hipStream_t s, Geom g, int r0, int r1, float alpha, float beta,
+                    const float2 *vin, float2 *vout) {
+  if (r1 <= r0) return;
+  hipLaunchKernelGGL(k_diffuse, grid_for(g, r0, r1), kBlock, 0, s, g, r0, r1, alpha, beta, vin, vout);
+}
+void launch_divergence(hipStream_t s, Geom g, int r0, int r1, const float2 *vel, float *div) {
+  if (r1 <= r0) return;
+  hipLaunchKernelGGL(k_divergence, grid_for(g, r0, r1), kBlock, 0, s, g, r0, r1, vel, div);
+}
+void launch_jacobi(hipStream_t s, Geom g, int r0, int r1, const float *pin, const float *div,
+                   float *pout) {
+  if (r1 <= r0) return;
+  hipLaunchKernelGGL(k_jacobi, grid_for(g, r0, r1), kBlock, 0, s, g, r0, r1, pin, div, pout);
+}
+void launch_project(hipStream_t s, Geom g, int r0, int r1, const float2 *vin, const float *p,
+                    float2 *vout) {
+  if (r1 <= r0) return;
+  hipLaunchKernelGGL(k_project, grid_for(g, r0, r1), kBlock, 0, s, g, r0, r1, vin, p, vout);
+}
+void launch_advect_dens(hipStream_t s, Geom g, int r0, int r1, float dt, const float2 *vel,
+                        const float4 *din, float4 *dout, int *flag) {
+  if (r1 <= r0) return;
+  hipLaunchKernelGGL(k_advect_dens, grid_for(g, r0, r1), kBlock, 0, s, g, r0, r1, dt, vel, din, dout,
+                     flag);
+}
+void launch_add_force(hipStream_t s, Geom g, int r0, int r1, float dt, float radius, float sx,
+                      float sy, float fx, float fy, float4 rgba, float2 *vel, float4 *dens) {
+  if (r1 <= r0) return;
+  hipLaunchKernelGGL(k_add_force, grid_for(g, r0, r1), kBlock, 0, s, g, r0, r1, dt, radius, sx, sy,
+                     fx, fy, rgba, vel, dens);
+}
+void launch_vorticity(hipStream_t s, Geom g, int r0, int r1, const float2 *vel, float *vort) {
+  if (r1 <= r0) return;
+  hipLaunchKernelGGL(k_vorticity, grid_for(g, r0, r1), kBlock, 0, s, g, r0, r1, vel, vort);
+}
+void launch_add_vorticity(hipStream_t s, Geom g, int r0, int r1, float dt, const float *vort,
+                          float2 *vel) {
+  if (r1 <= r0) return;
+  hipLaunchKernelGGL(k_add_vorticity, grid_for(g, r0, r1), kBlock, 0, s, g, r0, r1, dt, vort, vel);
+}

@@ -1,0 +1,189 @@
+/*
+ * fluid.h — C-ABI of the MI355X-native 2-D stable-fluids grid solver.
+ *
+ * This is the drop-in boundary for the per-timestep solver of
+ * deaklajos/Fluid-Simulation, FluidSimulation/kernel.cu.  The reference has no
+ * FFI: the path is a set of `void f(void)` host functions over file-scope
+ * globals (kernel.cu:435-479) called from GLUT callbacks.  Each export below
+ * names the reference host function it replaces (file:line under
+ * FluidSimulation/).  Plain pointers and sizes only; no C++/torch types.
+ *
+ * The header is implemented twice with identical semantics:
+ *   - fluid-simulation_amd/csrc/  -> libfluid_hip.so   (the product, gfx950 HIP)
+ *   - oracle/fluid_ref.c          -> liboracle_fluid.so (test infrastructure only)
+ *
+ * Field layout handed across the boundary (fluid_read / fluid_write): dense
+ * row-major, x fastest, index = x + y*n (kernel.cu:79, :398); velocity is
+ * interleaved (u,v) float2, density interleaved (r,g,b,a) float4, pressure and
+ * divergence plain float.  All arithmetic is fp32.
+ *
+ * Threading: one thread per context at a time (the reference is single
+ * threaded).  Several contexts may coexist.  Every call returns 0 on success
+ * or a negative FLUID_E_* code; nothing ever calls exit().
+ */
+#ifndef FLUID_H
+#define FLUID_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FLUID_API __attribute__((visibility("default")))
+
+/* ---- error codes ------------------------------------------------------- */
+enum {
+  FLUID_OK = 0,
+  FLUID_E_INVALID = -1,  /* bad argument (NULL, n < 4, unknown field, ...)    */
+  FLUID_E_NOMEM = -2,    /* host or device allocation failed                   */
+  FLUID_E_DEVICE = -3,   /* HIP runtime / kernel launch error (see fluid_last_error) */
+  FLUID_E_SIZE = -4,     /* caller buffer too small / larger than a stated maximum   */
+  FLUID_E_COMM = -5,     /* halo transport error                               */
+  FLUID_E_HALO = -6,     /* advection backtrace left the slab halo (multi-GPU) */
+  FLUID_E_UNSUPPORTED = -7
+};
+
+/* ---- fields (fluid_read / fluid_write) ---------------------------------- */
+enum {
+  FLUID_VELOCITY = 0,   /* float2 * n*n : velocityBuffer[inputVelocityBuffer]  kernel.cu:442-444 */
+  FLUID_DENSITY = 1,    /* float4 * n*n : densityBuffer[inputDensityBuffer]    kernel.cu:446-448 */
+  FLUID_PRESSURE = 2,   /* float  * n*n : pressureBuffer[inputPressureBuffer]  kernel.cu:451-453 */
+  FLUID_DIVERGENCE = 3, /* float  * n*n : divergenceBuffer                     kernel.cu:455-456 */
+  FLUID_VORTICITY = 4   /* float  * n*n : vorticityBuffer (only written when
+                           FLUID_FLAG_VORTICITY is set)                        kernel.cu:458-459 */
+};
+
+/* ---- flags --------------------------------------------------------------- */
+enum {
+  FLUID_FLAG_VORTICITY = 1u << 0, /* run simulateVorticity() between diffusion and projection
+                                     (kernel.cu:705, commented out in the reference => default off) */
+  FLUID_FLAG_NO_GRAPH = 1u << 1,  /* launch kernels directly instead of replaying a hipGraph   */
+  FLUID_FLAG_UNFUSED = 1u << 2    /* one kernel launch per reference kernel launch (25/step),
+                                     no temporal blocking; the straight mapping of kernel.cu   */
+};
+
+/*
+ * Parameters.  fluid_default_params() fills in the reference's literals:
+ *   n=512 (kernel.cu:438), diffusion_iters=10 (:584), pressure_iters=10 (:620),
+ *   dt=0.1f (:31), viscosity=0.01f (:181), splat_radius=0.001f (:368).
+ * The reference additionally needs n % 32 == 0 (kernel.cu:439-440, unguarded
+ * kernels); this library accepts any n >= 4.
+ *
+ * Slab decomposition (one process per GPU): the n x n domain is cut into
+ * slab_count row slabs; this context owns rows [n*slab_rank/slab_count,
+ * n*(slab_rank+1)/slab_count).  slab_count <= 1 means the whole domain.
+ * Halo rows travel either through RCCL inside the library (fluid_comm_init_rccl)
+ * or through the caller (fluid_halo_* below).
+ */
+typedef struct fluid_params {
+  int n;
+  int diffusion_iters;
+  int pressure_iters;
+  float dt;
+  float viscosity;
+  float splat_radius;
+  int device;          /* HIP device ordinal this context lives on            */
+  unsigned flags;      /* FLUID_FLAG_*                                        */
+  int slab_rank;       /* 0 .. slab_count-1                                   */
+  int slab_count;      /* 0 or 1 = no decomposition                           */
+  int halo_rows;       /* advection halo depth in rows (0 = library default)  */
+  int reserved[5];     /* must be zero                                        */
+} fluid_params;
+
+typedef struct fluid_ctx fluid_ctx;
+
+/* Fill *p with the reference literals (see above).  Never fails on non-NULL. */
+FLUID_API int fluid_default_params(fluid_params *p);
+
+/* initBuffers() + resetSimulation()  kernel.cu:481-528.
+ * Allocates every field on p->device and zeroes them.  p == NULL = defaults.
+ * The context is an opaque heap object; no globals. */
+FLUID_API int fluid_init(fluid_ctx **out, const fluid_params *p);
+
+/* Teardown, kernel.cu:914-934.  NULL is a no-op. */
+FLUID_API void fluid_destroy(fluid_ctx *ctx);
+
+/* resetSimulation()  kernel.cu:518-528 (the 'r' key, :819-821): zero the
+ * current velocity, pressure and density. */
+FLUID_API int fluid_reset(fluid_ctx *ctx);
+
+/* addForce() -> addForceCUDA  kernel.cu:687-699, :357-383.
+ * (sx,sy) are the NORMALIZED coordinates addForceCUDA receives (x/width,
+ * y/height, :689-690); (fx,fy) the raw force; rgba = densityColor (:507),
+ * caller-owned.  Applied to every cell, border included; ordered with respect
+ * to steps (same stream). */
+FLUID_API int fluid_add_source(fluid_ctx *ctx, float sx, float sy, float fx, float fy,
+                               const float rgba[4]);
+
+/* simulationStep()  kernel.cu:701-708, nsteps times.  Asynchronous: work is
+ * enqueued on the context's stream (a replayed hipGraph unless
+ * FLUID_FLAG_NO_GRAPH); no host synchronisation is implied. */
+FLUID_API int fluid_step(fluid_ctx *ctx, int nsteps);
+
+/* The four stage functions simulationStep() is made of, individually
+ * (kernel.cu:542-555, :582-602, :604-662, :664-685) and the optional
+ * simulateVorticity() (:557-580).  fluid_step == advect_velocity, diffuse,
+ * [vorticity], project, advect_density in that order. */
+FLUID_API int fluid_advect_velocity(fluid_ctx *ctx);
+FLUID_API int fluid_diffuse(fluid_ctx *ctx);
+FLUID_API int fluid_vorticity(fluid_ctx *ctx);
+FLUID_API int fluid_project(fluid_ctx *ctx);
+FLUID_API int fluid_advect_density(fluid_ctx *ctx);
+
+/* D2H half of visualizationStep()  kernel.cu:753.  Copies the CURRENT
+ * ping-pong half of `field` (kernel.cu:715, :727, :740) into dst (dense,
+ * row-major, owned rows only when slab-decomposed) and synchronises the stream
+ * (the reference's only sync point is this copy).  dst_bytes must be at least
+ * rows*n*sizeof(element). */
+FLUID_API int fluid_read(fluid_ctx *ctx, int field, void *dst, size_t dst_bytes);
+
+/* Inverse of fluid_read (checkpoint restore / test state injection); no
+ * counterpart in the reference, whose state lives only in device arrays. */
+FLUID_API int fluid_write(fluid_ctx *ctx, int field, const void *src, size_t src_bytes);
+
+/* cudaDeviceSynchronize analogue for this context's stream, kernel.cu:914. */
+FLUID_API int fluid_sync(fluid_ctx *ctx);
+
+/* Geometry of this context: grid edge, first owned row, number of owned rows. */
+FLUID_API int fluid_geometry(const fluid_ctx *ctx, int *n, int *row0, int *rows);
+
+/* Human-readable text for a FLUID_E_* code; never NULL. */
+FLUID_API const char *fluid_strerror(int code);
+/* Detail of the last FLUID_E_DEVICE / FLUID_E_COMM on this context ("" if none). */
+FLUID_API const char *fluid_last_error(const fluid_ctx *ctx);
+
+/* ---- measurement hooks (bench.py; replaces nothing in the reference, which
+ *      has no timers: SURVEY.md section 5) ----------------------------------- */
+
+/* Enqueue nsteps steps bracketed by HIP events on the context's own stream,
+ * wait for them, and return the elapsed device time in milliseconds. */
+FLUID_API int fluid_time_steps(fluid_ctx *ctx, int nsteps, float *ms_out);
+
+#define FLUID_MAX_KERNEL_STATS 16
+typedef struct fluid_kernel_stat {
+  char name[48];        /* kernel name as it appears in a rocprofv3 trace       */
+  int launches;         /* launches in the profiled steps                       */
+  float total_ms;       /* sum of launch durations (HIP events, own stream)     */
+  double alg_bytes;     /* algorithmic bytes per launch  */
+} fluid_kernel_stat;
+
+/* Run nsteps steps with direct launches, each launch bracketed by HIP events
+ * on the context's stream; fill stats[0..*count).  Results are identical to
+ * fluid_step. */
+FLUID_API int fluid_profile_steps(fluid_ctx *ctx, int nsteps, fluid_kernel_stat *stats,
+                                  int max_stats, int *count);
+
+/* ---- caller-provided stream ------------------------------------------------ */
+
+/* The context's hipStream_t (as void*).  fluid_set_stream makes the context
+ * enqueue on a caller-owned stream instead (e.g. torch's current stream, so
+ * torch.distributed halo transfers are ordered with the kernels); NULL restores
+ * the context's own stream.  Cached graphs are dropped. */
+FLUID_API void *fluid_stream(fluid_ctx *ctx);
+FLUID_API int fluid_set_stream(fluid_ctx *ctx, void *hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLUID_H */
