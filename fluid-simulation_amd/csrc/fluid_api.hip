@@ -10,6 +10,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <new>
@@ -46,6 +47,8 @@ struct fluid_ctx {
   float alpha = 0.f, beta = 0.f;  // diffusion constants, kernel.cu:182-183
   hipStream_t own_stream = nullptr, stream = nullptr;
   std::map<int, GraphEntry> graphs;
+  // temporal-blocking plan (fused path): sweeps per launch, columns per lane, target waves
+  int tb_kj = 8, tb_kd = 5, tb_cj = 4, tb_cd = 2, tb_waves = 4096;
   bool prof = false;
   std::vector<hipEvent_t> ev_pool;
   size_t ev_used = 0;
@@ -128,9 +131,51 @@ void enq_advect_velocity(fluid_ctx *c) {
   c->vin ^= 1;
 }
 
+int env_int(const char *name, int dflt) {
+  const char *v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
+}
+
+// Largest instantiated sweep count <= min(left, kmax)  (fluid_kernels_tb.hip TB_DISPATCH_K).
+int next_pass(int left, int kmax) {
+  static const int ks[] = {10, 8, 5, 4, 2, 1};
+  for (int k : ks)
+    if (k <= left && k <= kmax) return k;
+  return 1;
+}
+
+// Rows per wave so that the launch has about tb_waves waves.
+int tb_chunk(const fluid_ctx *c, int k, int cols, int rows) {
+  const int hx = (k + cols - 1) / cols * cols;
+  const int vw = 64 * cols - 2 * hx;
+  const int strips = (c->g.n + vw - 1) / vw;
+  const int chunks = c->tb_waves / strips > 1 ? c->tb_waves / strips : 1;
+  int chunk = (rows + chunks - 1) / chunks;
+  if (chunk < 4 * k) chunk = 4 * k;  // keep the y-halo recompute below ~1/3
+  return chunk;
+}
+
+bool use_tb(const fluid_ctx *c, int cols) {
+  return !(c->prm.flags & FLUID_FLAG_UNFUSED) && tb_supported(c->g.n, cols);
+}
+
 // simulateDiffusion()  kernel.cu:582-602
 void enq_diffuse(fluid_ctx *c) {
   const double cells = (double)cells_owned(c);
+  if (use_tb(c, c->tb_cd)) {
+    for (int left = c->prm.diffusion_iters; left > 0;) {
+      const int k = next_pass(left, c->tb_kd);
+      ProfScope p(c, K_DIFFUSE_TB, 16.0 * k * cells);
+      launch_diffuse_tb(c->stream, c->g, c->own_r0, c->own_r0 + c->rows, k, c->tb_cd,
+                        tb_chunk(c, k, c->tb_cd, c->rows), c->alpha, c->beta, c->vel[c->vin],
+                        c->vel[c->vin ^ 1]);
+      c->vin ^= 1;
+      left -= k;
+    }
+    // (the reference flips buffers once per sweep, kernel.cu:600; which physical buffer holds
+    // the current iterate is not observable through the ABI)
+    return;
+  }
   for (int i = 0; i < c->prm.diffusion_iters; ++i) {
     ProfScope p(c, K_DIFFUSE, 16.0 * cells);
     launch_diffuse(c->stream, c->g, c->own_r0, c->own_r0 + c->rows, c->alpha, c->beta,
@@ -164,10 +209,21 @@ void enq_project(fluid_ctx *c) {
   // resetPressure()  kernel.cu:530-540: only the pressure clear is live (the
   // other two targets are overwritten before they are read).
   (void)hipMemsetAsync(c->prs[c->pin], 0, cells_local(c) * sizeof(float), c->stream);
-  for (int i = 0; i < c->prm.pressure_iters; ++i) {
-    ProfScope p(c, K_JACOBI, 12.0 * cells);
-    launch_jacobi(c->stream, c->g, r0, r1, c->prs[c->pin], c->div, c->prs[c->pin ^ 1]);
-    c->pin ^= 1;
+  if (use_tb(c, c->tb_cj)) {
+    for (int left = c->prm.pressure_iters; left > 0;) {
+      const int k = next_pass(left, c->tb_kj);
+      ProfScope p(c, K_JACOBI_TB, 12.0 * k * cells);
+      launch_jacobi_tb(c->stream, c->g, r0, r1, k, c->tb_cj, tb_chunk(c, k, c->tb_cj, c->rows),
+                       c->prs[c->pin], c->div, c->prs[c->pin ^ 1]);
+      c->pin ^= 1;
+      left -= k;
+    }
+  } else {
+    for (int i = 0; i < c->prm.pressure_iters; ++i) {
+      ProfScope p(c, K_JACOBI, 12.0 * cells);
+      launch_jacobi(c->stream, c->g, r0, r1, c->prs[c->pin], c->div, c->prs[c->pin ^ 1]);
+      c->pin ^= 1;
+    }
   }
   {
     ProfScope p(c, K_PROJECT, 20.0 * cells);
@@ -280,6 +336,12 @@ int fluid_init(fluid_ctx **out, const fluid_params *p) {
   c->row0 = 0;
   c->rows = prm.n;
   c->own_r0 = 0;
+  // tuning knobs (defaults chosen from measurements); results do not depend on them
+  c->tb_kj = env_int("FLUID_TB_KJ", c->tb_kj);
+  c->tb_kd = env_int("FLUID_TB_KD", c->tb_kd);
+  c->tb_cj = env_int("FLUID_TB_CJ", c->tb_cj);
+  c->tb_cd = env_int("FLUID_TB_CD", c->tb_cd);
+  c->tb_waves = env_int("FLUID_TB_WAVES", c->tb_waves);
   c->alpha = 1.0f / (prm.viscosity * prm.dt);  // kernel.cu:182, fp32 at run time
   c->beta = 1.0f / (4.0f + c->alpha);          // kernel.cu:183
   int rc = [&]() -> int {
@@ -480,8 +542,10 @@ int fluid_profile_steps(fluid_ctx *c, int nsteps, fluid_kernel_stat *stats, int 
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev_pool[r.e0], c->ev_pool[r.e1]));
     acc[r.kid].launches += 1;
     acc[r.kid].total_ms += ms;
-    acc[r.kid].alg_bytes = r.bytes;
+    acc[r.kid].alg_bytes += r.bytes;
   }
+  for (int i = 0; i < K_COUNT; ++i)
+    if (acc[i].launches) acc[i].alg_bytes /= acc[i].launches;  // mean per launch
   int k = 0;
   for (int i = 0; i < K_COUNT && k < max_stats; ++i) {
     if (!acc[i].launches) continue;

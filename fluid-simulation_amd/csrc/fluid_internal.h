@@ -49,3 +49,13 @@ void launch_add_force(hipStream_t s, Geom g, int r0, int r1, float dt, float rad
 void launch_vorticity(hipStream_t s, Geom g, int r0, int r1, const float2 *vel, float *vort);
 void launch_add_vorticity(hipStream_t s, Geom g, int r0, int r1, float dt, const float *vort,
                           float2 *vel);
+
+// ---- temporally blocked sweeps (fluid_kernels_tb.hip) -----------------------
+// k sweeps per launch; cols = columns per lane (2 or 4); chunk = rows a wave
+// streams.  Return false when the shape is unsupported (caller falls back to
+// the straight kernels): n % cols != 0 or k not instantiated.
+bool tb_supported(int n, int cols);
+bool launch_jacobi_tb(hipStream_t s, Geom g, int r0, int r1, int k, int cols, int chunk,
+                      const float *pin, const float *div, float *pout);
+bool launch_diffuse_tb(hipStream_t s, Geom g, int r0, int r1, int k, int cols, int chunk,
+                       float alpha, float beta, const float2 *vin, float2 *vout);
