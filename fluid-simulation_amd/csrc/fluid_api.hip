@@ -48,7 +48,7 @@ struct fluid_ctx {
   hipStream_t own_stream = nullptr, stream = nullptr;
   std::map<int, GraphEntry> graphs;
   // temporal-blocking plan (fused path): sweeps per launch, columns per lane, target waves
-  int tb_kj = 8, tb_kd = 5, tb_cj = 4, tb_cd = 2, tb_waves = 4096;
+  int tb_kj = 10, tb_kd = 5, tb_cj = 2, tb_cd = 2, tb_waves = 4096;
   bool prof = false;
   std::vector<hipEvent_t> ev_pool;
   size_t ev_used = 0;

@@ -35,6 +35,18 @@ __device__ __forceinline__ float from_right(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xF, 0xF, false));
 }
 
+// Exact negate (sign-bit flip) the optimiser cannot see through.  ROCm 7.2 hipcc
+// miscompiles fneg(select(uniform, rowA, rowB)) on 2-wide float vectors in this
+// kernel: one half of the packed negate is dropped (seen in the .s as
+// v_cndmask, v_cndmask, v_xor on one register only) and the y-border rows come
+// out with the wrong sign in one of the three unrolled phases.  Border paths
+// only, so the opaque form costs nothing measurable.
+__device__ __forceinline__ float neg_opaque(float x) {
+  float r;
+  asm("v_xor_b32 %0, 0x80000000, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+
 template <int C> struct Row { float v[C]; };
 
 template <int C>
@@ -77,97 +89,8 @@ template <int K, int C> struct StripGeom {
   static_assert(VW > 0, "strip too narrow for this K");
 };
 
-// ---------------------------------------------------------------------------
-// pressureJacobi x K   (kernel.cu:291-324)
-// ---------------------------------------------------------------------------
-template <int C, bool XEDGE>
-__device__ __forceinline__ Row<C> jacobi_row(const Row<C> &a, const Row<C> &b, const Row<C> &n,
-                                             const Row<C> &d, int r, int x0, int N) {
-  Row<C> o;
-  if (r <= 0 || r >= N - 1) {  // wave-uniform
-#pragma unroll
-    for (int c = 0; c < C; ++c) o.v[c] = (r == 0) ? -n.v[c] : -a.v[c];  // kernel.cu:321-322
-    return o;
-  }
-  const float lft = from_left(b.v[C - 1]);
-  const float rgt = from_right(b.v[0]);
-#pragma unroll
-  for (int c = 0; c < C; ++c) {
-    const float vL = c > 0 ? b.v[c - 1] : lft;
-    const float vR = c < C - 1 ? b.v[c + 1] : rgt;
-    float s = ((((vL + vR) + a.v[c]) + n.v[c]) + (-1.0f) * d.v[c]) * 0.25f;  // kernel.cu:313
-    if (XEDGE) {
-      const int x = x0 + c;
-      if (x == 0) s = -vR;      // kernel.cu:319
-      if (x == N - 1) s = -vL;  // kernel.cu:320
-    }
-    o.v[c] = s;
-  }
-  return o;
-}
+struct NoAux {};
 
-template <int K, int C, bool XEDGE>
-__device__ __forceinline__ void jacobi_stream(Geom g, int ya, int yb, int x0, bool in_dom,
-                                              bool st_ok, const float *__restrict__ pin,
-                                              const float *__restrict__ div,
-                                              float *__restrict__ pout) {
-  Row<C> a[K], b[K], dv[K];
-#pragma unroll
-  for (int l = 0; l < K; ++l) { a[l] = zero_row<C>(); b[l] = zero_row<C>(); dv[l] = zero_row<C>(); }
-  const int N = g.n;
-  auto row_ok = [&](int t) { return in_dom && t >= 0 && t < N && t - g.ybase >= 0 && t - g.ybase < g.L; };
-  auto ld = [&](const float *f, int t) {
-    return row_ok(t) ? load_row<C>(f + (size_t)(t - g.ybase) * N + x0) : zero_row<C>();
-  };
-  const int t0 = ya - K, t1 = yb + K;
-  Row<C> cur_p = ld(pin, t0), cur_d = ld(div, t0);
-  Row<C> nxt_p = ld(pin, t0 + 1), nxt_d = ld(div, t0 + 1);
-  Row<C> prev_d = zero_row<C>();
-  for (int t = t0; t < t1; ++t) {
-    Row<C> ld_p = ld(pin, t + 2), ld_d = ld(div, t + 2);  // prefetch two rows ahead
-#pragma unroll
-    for (int l = K - 1; l > 0; --l) dv[l] = dv[l - 1];
-    dv[0] = prev_d;  // div row t-1
-    Row<C> n = cur_p;  // level 0, row t
-#pragma unroll
-    for (int l = 0; l < K; ++l) {
-      Row<C> o = jacobi_row<C, XEDGE>(a[l], b[l], n, dv[l], t - l - 1, x0, N);
-      a[l] = b[l];
-      b[l] = n;
-      n = o;
-    }
-    const int ro = t - K;  // level K row just produced
-    if (st_ok && ro >= ya && ro < yb) store_row<C>(pout + (size_t)(ro - g.ybase) * N + x0, n);
-    prev_d = cur_d;
-    cur_p = nxt_p; cur_d = nxt_d;
-    nxt_p = ld_p; nxt_d = ld_d;
-  }
-}
-
-template <int K, int C>
-__global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK) void k_jacobi_tb(
-    Geom g, int r0, int r1, int chunk, const float *__restrict__ pin,
-    const float *__restrict__ div, float *__restrict__ pout) {
-  using SG = StripGeom<K, C>;
-  const int lane = threadIdx.x & (WAVE - 1);
-  const int strip = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
-  const int xs = strip * SG::VW;
-  if (xs >= g.n) return;  // whole wave
-  const int x0 = xs - SG::HX + lane * C;
-  const bool in_dom = x0 >= 0 && x0 < g.n;
-  const bool st_ok = in_dom && lane * C >= SG::HX && lane * C < SG::HX + SG::VW;
-  const int ya = g.ybase + r0 + blockIdx.y * chunk;
-  const int yb = min(ya + chunk, g.ybase + r1);
-  const bool xedge = xs == 0 || xs + SG::VW + SG::HX >= g.n;  // wave-uniform
-  if (xedge)
-    jacobi_stream<K, C, true>(g, ya, yb, x0, in_dom, st_ok, pin, div, pout);
-  else
-    jacobi_stream<K, C, false>(g, ya, yb, x0, in_dom, st_ok, pin, div, pout);
-}
-
-// ---------------------------------------------------------------------------
-// diffusion x K   (kernel.cu:173-205), float2 field: two planes per column
-// ---------------------------------------------------------------------------
 template <int C> struct Row2 { float u[C], w[C]; };  // (x, y) components of C columns
 
 template <int C>
@@ -199,80 +122,208 @@ __device__ __forceinline__ void store_row2(float2 *p, const Row2<C> &r) {
     reinterpret_cast<float4 *>(p)[c / 2] = make_float4(r.u[c], r.w[c], r.u[c + 1], r.w[c + 1]);
 }
 
-template <int C, bool XEDGE>
-__device__ __forceinline__ Row2<C> diffuse_row(const Row2<C> &a, const Row2<C> &b, const Row2<C> &n,
-                                               int r, int x0, int N, float alpha, float beta) {
-  if (r <= 0 || r >= N - 1) return b;  // wave-uniform; border copies through, kernel.cu:201-203
-  Row2<C> o;
-  const float lu = from_left(b.u[C - 1]), lw = from_left(b.w[C - 1]);
-  const float ru = from_right(b.u[0]), rw = from_right(b.w[0]);
-#pragma unroll
-  for (int c = 0; c < C; ++c) {
-    const float uL = c > 0 ? b.u[c - 1] : lu, wL = c > 0 ? b.w[c - 1] : lw;
-    const float uR = c < C - 1 ? b.u[c + 1] : ru, wR = c < C - 1 ? b.w[c + 1] : rw;
-    float su = ((((uL + uR) + a.u[c]) + n.u[c]) + alpha * b.u[c]) * beta;  // kernel.cu:195
-    float sw = ((((wL + wR) + a.w[c]) + n.w[c]) + alpha * b.w[c]) * beta;
-    if (XEDGE) {
-      const int x = x0 + c;
-      if (x == 0 || x == N - 1) { su = b.u[c]; sw = b.w[c]; }
-    }
-    o.u[c] = su;
-    o.w[c] = sw;
-  }
-  return o;
-}
+// ---------------------------------------------------------------------------
+// Per-row update rules.  apply<XEDGE, YCHK>(a, b, n, d, r, ...) produces row r
+// of the next level from rows r-1 (a), r (b), r+1 (n) of the current level.
+// XEDGE: the strip touches x == 0 or x == N-1.  YCHK: r may be <= 0 or >= N-1
+// (wave-uniform test); the steady-state instantiation has neither.
+// ---------------------------------------------------------------------------
 
-template <int K, int C, bool XEDGE>
-__device__ __forceinline__ void diffuse_stream(Geom g, int ya, int yb, int x0, bool in_dom,
-                                               bool st_ok, float alpha, float beta,
-                                               const float2 *__restrict__ vin,
-                                               float2 *__restrict__ vout) {
-  Row2<C> a[K], b[K];
+// pressureJacobi, kernel.cu:291-324
+template <int C> struct JacobiOp {
+  using R = Row<C>;
+  using A = Row<C>;  // divergence row
+  using Elem = float;
+  struct P { const float *in; const float *aux; float *out; };
+  static __device__ __forceinline__ R zero() { return zero_row<C>(); }
+  static __device__ __forceinline__ A zero_aux() { return zero_row<C>(); }
+  static __device__ __forceinline__ R load(const P &p, size_t off) { return load_row<C>(p.in + off); }
+  static __device__ __forceinline__ A load_aux(const P &p, size_t off) { return load_row<C>(p.aux + off); }
+  static __device__ __forceinline__ void store(const P &p, size_t off, const R &r) { store_row<C>(p.out + off, r); }
+
+  template <bool XEDGE, bool YCHK>
+  static __device__ __forceinline__ R apply(const R &a, const R &b, const R &n, const A &d, int r,
+                                            int x0, int N, const P &) {
+    R o;
+    if (YCHK && (r <= 0 || r >= N - 1)) {  // wave-uniform
 #pragma unroll
-  for (int l = 0; l < K; ++l) { a[l] = zero_row2<C>(); b[l] = zero_row2<C>(); }
-  const int N = g.n;
-  auto ld = [&](int t) {
-    const bool ok = in_dom && t >= 0 && t < N && t - g.ybase >= 0 && t - g.ybase < g.L;
-    return ok ? load_row2<C>(vin + (size_t)(t - g.ybase) * N + x0) : zero_row2<C>();
-  };
-  const int t0 = ya - K, t1 = yb + K;
-  Row2<C> cur = ld(t0), nxt = ld(t0 + 1);
-  for (int t = t0; t < t1; ++t) {
-    Row2<C> pre = ld(t + 2);
-    Row2<C> n = cur;
+      for (int c = 0; c < C; ++c)  // y == 0: -p[x,1]; y == N-1: -p[x,N-2]  (kernel.cu:321-322)
+        o.v[c] = neg_opaque(r <= 0 ? n.v[c] : a.v[c]);
+      return o;
+    }
+    const float lft = from_left(b.v[C - 1]);
+    const float rgt = from_right(b.v[0]);
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const float vL = c > 0 ? b.v[c - 1] : lft;
+      const float vR = c < C - 1 ? b.v[c + 1] : rgt;
+      float s = ((((vL + vR) + a.v[c]) + n.v[c]) + (-1.0f) * d.v[c]) * 0.25f;  // kernel.cu:313
+      if (XEDGE) {
+        const int x = x0 + c;
+        if (x == 0) s = neg_opaque(vR);      // kernel.cu:319
+        if (x == N - 1) s = neg_opaque(vL);  // kernel.cu:320
+      }
+      o.v[c] = s;
+    }
+    return o;
+  }
+};
+
+// diffusion, kernel.cu:173-205 (float2 field: two planes per column)
+template <int C> struct DiffuseOp {
+  using R = Row2<C>;
+  using A = NoAux;
+  struct P { const float2 *in; float2 *out; float alpha, beta; };
+  static __device__ __forceinline__ R zero() { return zero_row2<C>(); }
+  static __device__ __forceinline__ A zero_aux() { return NoAux{}; }
+  static __device__ __forceinline__ R load(const P &p, size_t off) { return load_row2<C>(p.in + off); }
+  static __device__ __forceinline__ A load_aux(const P &, size_t) { return NoAux{}; }
+  static __device__ __forceinline__ void store(const P &p, size_t off, const R &r) { store_row2<C>(p.out + off, r); }
+
+  template <bool XEDGE, bool YCHK>
+  static __device__ __forceinline__ R apply(const R &a, const R &b, const R &n, const A &, int r,
+                                            int x0, int N, const P &p) {
+    if (YCHK && (r <= 0 || r >= N - 1)) return b;  // border copies through, kernel.cu:201-203
+    R o;
+    const float alpha = p.alpha, beta = p.beta;
+    const float lu = from_left(b.u[C - 1]), lw = from_left(b.w[C - 1]);
+    const float ru = from_right(b.u[0]), rw = from_right(b.w[0]);
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const float uL = c > 0 ? b.u[c - 1] : lu, wL = c > 0 ? b.w[c - 1] : lw;
+      const float uR = c < C - 1 ? b.u[c + 1] : ru, wR = c < C - 1 ? b.w[c + 1] : rw;
+      float su = ((((uL + uR) + a.u[c]) + n.u[c]) + alpha * b.u[c]) * beta;  // kernel.cu:195
+      float sw = ((((wL + wR) + a.w[c]) + n.w[c]) + alpha * b.w[c]) * beta;
+      if (XEDGE) {
+        const int x = x0 + c;
+        if (x == 0 || x == N - 1) { su = b.u[c]; sw = b.w[c]; }
+      }
+      o.u[c] = su;
+      o.w[c] = sw;
+    }
+    return o;
+  }
+};
+
+// ---------------------------------------------------------------------------
+// The register pipeline.  Level l keeps three row slots s[l][0..2] used as a
+// ring: in a step of phase J the slots (J, J+1, J+2) mod 3 hold rows
+// (r-1, r, r+1); the producer (the load for level 0, level l-1 otherwise)
+// writes the new row straight into slot (J+2) mod 3, so rows never move
+// between registers.  The time loop is unrolled by 3 so every slot index is a
+// compile-time constant.
+// ---------------------------------------------------------------------------
+template <class Op, int K, bool XEDGE> struct Pipe {
+  using R = typename Op::R;
+  using A = typename Op::A;
+  using P = typename Op::P;
+  R s[K + 1][3];
+  A dv[K];          // dv[l] = aux row needed by level l+1 this step (row t-l-1)
+  R q0, q1;         // prefetched level-0 rows t, t+1
+  A dq0, dq1, dprev;  // aux rows t, t+1, t-1
+  Geom g;
+  int x0, ya, yb;
+  bool in_dom, st_ok;
+
+  __device__ __forceinline__ bool row_ok(int t) const {
+    return in_dom && t >= 0 && t < g.n && t - g.ybase >= 0 && t - g.ybase < g.L;
+  }
+  __device__ __forceinline__ size_t off(int t) const { return (size_t)(t - g.ybase) * g.n + x0; }
+  __device__ __forceinline__ R ld(const P &p, int t) const { return row_ok(t) ? Op::load(p, off(t)) : Op::zero(); }
+  __device__ __forceinline__ A lda(const P &p, int t) const { return row_ok(t) ? Op::load_aux(p, off(t)) : Op::zero_aux(); }
+
+  __device__ __forceinline__ void init(const P &p, int t0) {
 #pragma unroll
     for (int l = 0; l < K; ++l) {
-      Row2<C> o = diffuse_row<C, XEDGE>(a[l], b[l], n, t - l - 1, x0, N, alpha, beta);
-      a[l] = b[l];
-      b[l] = n;
-      n = o;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) s[l][j] = Op::zero();
+      dv[l] = Op::zero_aux();
     }
-    const int ro = t - K;
-    if (st_ok && ro >= ya && ro < yb) store_row2<C>(vout + (size_t)(ro - g.ybase) * N + x0, n);
-    cur = nxt;
-    nxt = pre;
+    dprev = Op::zero_aux();
+    q0 = ld(p, t0); dq0 = lda(p, t0);
+    q1 = ld(p, t0 + 1); dq1 = lda(p, t0 + 1);
   }
+
+  template <int J, bool YCHK>
+  __device__ __forceinline__ R levels(const P &p, int t) {
+    R fin = Op::zero();
+#pragma unroll
+    for (int l = 0; l < K; ++l) {
+      R o = Op::template apply<XEDGE, YCHK>(s[l][J % 3], s[l][(J + 1) % 3], s[l][(J + 2) % 3], dv[l],
+                                            t - l - 1, x0, g.n, p);
+      if (l + 1 < K) s[l + 1][(J + 2) % 3] = o; else fin = o;
+    }
+    return fin;
+  }
+
+  template <int J>
+  __device__ __forceinline__ void step(const P &p, int t) {
+    R pre = ld(p, t + 2);  // prefetch two rows ahead
+    A dpre = lda(p, t + 2);
+    s[0][(J + 2) % 3] = q0;  // level 0, row t
+#pragma unroll
+    for (int l = K - 1; l > 0; --l) dv[l] = dv[l - 1];
+    dv[0] = dprev;  // aux row t-1
+    R fin;
+    if (t - K >= 1 && t - 1 <= g.n - 2) fin = levels<J, false>(p, t);  // every level's row is y-interior
+    else fin = levels<J, true>(p, t);
+    const int ro = t - K;  // level K row just produced
+    if (st_ok && ro >= ya && ro < yb) Op::store(p, off(ro), fin);
+    dprev = dq0;
+    q0 = q1; dq0 = dq1;
+    q1 = pre; dq1 = dpre;
+  }
+
+  __device__ __forceinline__ void run(const P &p) {
+    const int t0 = ya - K, t1 = yb + K;
+    init(p, t0);
+    for (int t = t0; t < t1; t += 3) {  // up to two surplus steps: loads and stores are guarded
+      step<0>(p, t);
+      step<1>(p, t + 1);
+      step<2>(p, t + 2);
+    }
+  }
+};
+
+template <class Op, int K, int C>
+__device__ __forceinline__ void tb_kernel_body(Geom g, int r0, int r1, int chunk,
+                                               const typename Op::P &p) {
+  using SG = StripGeom<K, C>;
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int strip = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+  const int xs = strip * SG::VW;
+  if (xs >= g.n) return;  // whole wave
+  const int x0 = xs - SG::HX + lane * C;
+  const bool in_dom = x0 >= 0 && x0 < g.n;  // n % C == 0: a lane's columns are all in or all out
+  const bool st_ok = in_dom && lane * C >= SG::HX && lane * C < SG::HX + SG::VW;
+  const int ya = g.ybase + r0 + blockIdx.y * chunk;
+  const int yb = min(ya + chunk, g.ybase + r1);
+  const bool xedge = xs == 0 || xs + SG::VW + SG::HX >= g.n;  // wave-uniform
+  if (xedge) {
+    Pipe<Op, K, true> pipe;
+    pipe.g = g; pipe.x0 = x0; pipe.ya = ya; pipe.yb = yb; pipe.in_dom = in_dom; pipe.st_ok = st_ok;
+    pipe.run(p);
+  } else {
+    Pipe<Op, K, false> pipe;
+    pipe.g = g; pipe.x0 = x0; pipe.ya = ya; pipe.yb = yb; pipe.in_dom = in_dom; pipe.st_ok = st_ok;
+    pipe.run(p);
+  }
+}
+
+template <int K, int C>
+__global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK) void k_jacobi_tb(
+    Geom g, int r0, int r1, int chunk, const float *__restrict__ pin,
+    const float *__restrict__ div, float *__restrict__ pout) {
+  typename JacobiOp<C>::P p{pin, div, pout};
+  tb_kernel_body<JacobiOp<C>, K, C>(g, r0, r1, chunk, p);
 }
 
 template <int K, int C>
 __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK) void k_diffuse_tb(
     Geom g, int r0, int r1, int chunk, float alpha, float beta, const float2 *__restrict__ vin,
     float2 *__restrict__ vout) {
-  using SG = StripGeom<K, C>;
-  const int lane = threadIdx.x & (WAVE - 1);
-  const int strip = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
-  const int xs = strip * SG::VW;
-  if (xs >= g.n) return;
-  const int x0 = xs - SG::HX + lane * C;
-  const bool in_dom = x0 >= 0 && x0 < g.n;
-  const bool st_ok = in_dom && lane * C >= SG::HX && lane * C < SG::HX + SG::VW;
-  const int ya = g.ybase + r0 + blockIdx.y * chunk;
-  const int yb = min(ya + chunk, g.ybase + r1);
-  const bool xedge = xs == 0 || xs + SG::VW + SG::HX >= g.n;
-  if (xedge)
-    diffuse_stream<K, C, true>(g, ya, yb, x0, in_dom, st_ok, alpha, beta, vin, vout);
-  else
-    diffuse_stream<K, C, false>(g, ya, yb, x0, in_dom, st_ok, alpha, beta, vin, vout);
+  typename DiffuseOp<C>::P p{vin, vout, alpha, beta};
+  tb_kernel_body<DiffuseOp<C>, K, C>(g, r0, r1, chunk, p);
 }
 
 template <int K, int C>

@@ -252,3 +252,31 @@ def test_temporal_blocking_plans_bit_exact(pkg, hip, oracle, plan, monkeypatch):
         a, b = read_all(gpu, pkg), read_all(ref, pkg)
         for f in ("velocity", "pressure", "divergence"):
             assert_bit_equal(a[f], b[f], f"{stage}/{f} plan={plan}")
+
+
+@pytest.mark.parametrize("cols", [2, 4])
+@pytest.mark.parametrize("k", [1, 2, 4, 5, 8, 10])
+def test_temporal_blocking_every_phase_at_the_borders(pkg, hip, oracle, k, cols, monkeypatch):
+    """The register pipeline is unrolled by three; which unrolled copy meets the y == N-1 border
+    depends on (N + k) mod 3.  Three grid sizes cover all copies, and passes 2 and 3 start from a
+    non-zero iterate (a first pass from p == 0 hides level-0 mistakes).  This is the case that
+    caught a hipcc miscompile of the border negate (see fluid_kernels_tb.hip)."""
+    if k == 10 and cols == 4:
+        monkeypatch.setenv("FLUID_TB_CD", "2")  # diffusion K=10 x 4 columns exceeds the VGPR file
+    else:
+        monkeypatch.setenv("FLUID_TB_CD", str(cols))
+    monkeypatch.setenv("FLUID_TB_KJ", str(k))
+    monkeypatch.setenv("FLUID_TB_CJ", str(cols))
+    monkeypatch.setenv("FLUID_TB_KD", str(k))
+    monkeypatch.setenv("FLUID_TB_WAVES", "1")  # one chunk per strip: the pipeline runs top to bottom
+    for n in (96, 100, 104):
+        gpu, ref = pair(pkg, hip, oracle, n, diffusion_iters=3 * k, pressure_iters=3 * k)
+        state = random_state(n, seed=n + k, vmax=20.0)
+        for stage in ("diffuse", "project"):
+            load_state(gpu, pkg, *state)
+            load_state(ref, pkg, *state)
+            getattr(gpu, stage)()
+            getattr(ref, stage)()
+            a, b = read_all(gpu, pkg), read_all(ref, pkg)
+            for f in ("velocity", "pressure"):
+                assert_bit_equal(a[f], b[f], f"{stage}/{f} n={n} k={k} cols={cols}")
