@@ -1,0 +1,63 @@
+"""Multi-GPU leg of bench.py: one rank per GPU (torch.distributed.run), row slabs, RCCL halos."""
+import json
+import os
+import time
+
+
+def run_multi(pkg, args, n, D, J, flags):
+    import torch
+    import torch.distributed as dist
+    from fluid_simulation_amd.slab import SlabSim
+    from bench import HBM_PEAK_GBPS, seeded_warm_state
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", str(args.gpus)))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
+                         f"--nproc-per-node {args.gpus}")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    torch.cuda.set_device(local)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    sim = SlabSim(pkg, n, rank=rank, world=world, device_index=local, diffusion_iters=D,
+                  pressure_iters=J, flags=flags)
+    seeded_warm_state(pkg, sim)          # every rank applies the same splats to its own rows
+    sim.step(args.warmup)
+    sim.sync()
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    sim.step(args.steps)
+    sim.sync()
+    torch.cuda.synchronize()
+    dist.barrier()
+    wall = time.perf_counter() - t0
+    t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    wall = float(t.item())
+
+    if rank == 0:
+        t_step = wall / args.steps
+        bpc = pkg.alg_bytes_per_cell(D, J)
+        plan = pkg.FluidLib().slab_plan(n, 0, world, diffusion_iters=D, pressure_iters=J)
+        out = {
+            "metric": "cell-updates/sec per full timestep (GCUPS)",
+            "value": round(n * n / t_step / 1e9, 4), "unit": "GCUPS", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(t_step * 1e3, 5),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (seeded splats, SURVEY.md 8d)",
+            "config": {"workload": f"{n}x{n} grid, D={D} diffusion + J={J} Jacobi sweeps per step",
+                       "name": args.workload, "path": "unfused" if args.unfused else "fused",
+                       "decomposition": f"{world} row slabs of {plan['rows']} rows, one halo exchange per "
+                                        f"step ({plan['halo_vel']} velocity + {plan['halo_dens']} density rows "
+                                        f"per neighbour) over RCCL send/recv"},
+            "step_alg_bytes_per_cell": bpc,
+            "step_effective_GBps": round(bpc * n * n / t_step / 1e9, 1),
+            "step_frac_of_hbm_peak": round(bpc * n * n / t_step / 1e9 / (HBM_PEAK_GBPS * world), 4),
+            "halo_bytes_per_step_per_rank": sim.ex.bytes_per_step,
+        }
+        print(json.dumps(out), flush=True)
+    sim.close()
+    dist.barrier()
+    dist.destroy_process_group()

@@ -25,6 +25,7 @@ ABI_SYMBOLS = [
     "fluid_advect_density", "fluid_read", "fluid_write", "fluid_sync", "fluid_geometry",
     "fluid_strerror", "fluid_last_error", "fluid_time_steps", "fluid_profile_steps",
     "fluid_stream", "fluid_set_stream",
+    "fluid_slab_plan", "fluid_halo_bytes", "fluid_halo_pack", "fluid_halo_unpack",
 ]
 
 
@@ -35,6 +36,14 @@ class FluidParams(C.Structure):
         ("device", C.c_int), ("flags", C.c_uint), ("slab_rank", C.c_int), ("slab_count", C.c_int),
         ("halo_rows", C.c_int), ("reserved", C.c_int * 5),
     ]
+
+
+class SlabInfo(C.Structure):
+    _fields_ = [(k, C.c_int) for k in ("n", "row0", "rows", "halo_vel", "halo_dens", "store_row0",
+                                       "store_rows", "has_lo", "has_hi")]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
 
 
 class KernelStat(C.Structure):
@@ -97,6 +106,25 @@ class FluidLib:
             C.POINTER(C.c_int), required=False)
         sig("fluid_stream", P, P, required=False)
         sig("fluid_set_stream", C.c_int, P, P, required=False)
+        sig("fluid_slab_plan", C.c_int, C.POINTER(FluidParams), C.POINTER(SlabInfo), required=False)
+        sig("fluid_halo_bytes", C.c_size_t, P, C.c_int, required=False)
+        sig("fluid_halo_pack", C.c_int, P, C.c_int, P, required=False)
+        sig("fluid_halo_unpack", C.c_int, P, C.c_int, P, required=False)
+
+    def slab_plan(self, n, slab_rank, slab_count, *, diffusion_iters=None, pressure_iters=None,
+                  halo_rows=0) -> dict:
+        """fluid_slab_plan: pure host arithmetic, needs no GPU."""
+        p = self.default_params()
+        p.n, p.slab_rank, p.slab_count, p.halo_rows = n, slab_rank, slab_count, halo_rows
+        if diffusion_iters is not None:
+            p.diffusion_iters = diffusion_iters
+        if pressure_iters is not None:
+            p.pressure_iters = pressure_iters
+        info = SlabInfo()
+        rc = self.dll.fluid_slab_plan(C.byref(p), C.byref(info))
+        if rc:
+            raise FluidError(rc, "fluid_slab_plan", self.dll.fluid_strerror(rc).decode())
+        return info.as_dict()
 
     def default_params(self) -> FluidParams:
         p = FluidParams()
@@ -244,6 +272,17 @@ class FluidSim:
         return [dict(name=stats[i].name.decode(), launches=stats[i].launches,
                      total_ms=stats[i].total_ms, alg_bytes=stats[i].alg_bytes)
                 for i in range(cnt.value)]
+
+    # -- slab halos -----------------------------------------------------------------
+    def halo_bytes(self, direction: int) -> int:
+        return self.lib.dll.fluid_halo_bytes(self._h, direction)
+
+    def halo_pack(self, direction: int, dev_ptr: int):
+        self._chk(self.lib.dll.fluid_halo_pack(self._h, direction, C.c_void_p(dev_ptr)), "fluid_halo_pack")
+
+    def halo_unpack(self, direction: int, dev_ptr: int):
+        self._chk(self.lib.dll.fluid_halo_unpack(self._h, direction, C.c_void_p(dev_ptr)),
+                  "fluid_halo_unpack")
 
     def stream(self) -> int:
         return self.lib.dll.fluid_stream(self._h) or 0

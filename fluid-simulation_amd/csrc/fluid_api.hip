@@ -37,6 +37,8 @@ struct fluid_ctx {
   Geom g;
   int row0 = 0, rows = 0;  // owned global rows [row0, row0 + rows)
   int own_r0 = 0;          // local row of the first owned row
+  int halo_vel = 0, halo_dens = 0, adv_rows = 0;  // slab halos (fluid_slab_plan); 0 when whole-domain
+  bool slab = false, has_lo = false, has_hi = false;
   float2 *vel[2] = {nullptr, nullptr};   // velocityBufferArray[2]  kernel.cu:443-444
   float4 *dens[2] = {nullptr, nullptr};  // densityBufferArray[2]   kernel.cu:447-448
   float *prs[2] = {nullptr, nullptr};    // pressureBufferArray[2]  kernel.cu:452-453
@@ -122,11 +124,22 @@ struct ProfScope {
 // ---- stage enqueue: the reference's host stage functions --------------------
 // Row ranges are local rows; for a whole-domain context [0, n).
 
-// simulateAdvection()  kernel.cu:542-555
-void enq_advect_velocity(fluid_ctx *c) {
+// Local row range: the owned rows widened by `m` rows into each halo (clipped to
+// what is stored; at a domain edge nothing is stored beyond it).  Slab contexts
+// recompute the step's dependency cone in their halos (fluid.h, fluid_slab_plan);
+// whole-domain contexts have no halo, so every range is the owned rows.
+struct Range { int r0, r1; };
+Range widened(const fluid_ctx *c, int m) {
+  const int lo = c->own_r0, hi = c->g.L - c->own_r0 - c->rows;  // halo rows stored below / above
+  return Range{c->own_r0 - (m < lo ? m : lo), c->own_r0 + c->rows + (m < hi ? m : hi)};
+}
+
+// simulateAdvection()  kernel.cu:542-555.  out_m: halo margin the result must cover.
+void enq_advect_velocity(fluid_ctx *c, int out_m) {
   const double cells = (double)cells_owned(c);
   ProfScope p(c, K_ADVECT_VEL, 16.0 * cells);
-  launch_advect_vel(c->stream, c->g, c->own_r0, c->own_r0 + c->rows, c->prm.dt, c->vel[c->vin],
+  const Range r = widened(c, out_m);
+  launch_advect_vel(c->stream, c->g, r.r0, r.r1, 0, c->g.L, c->prm.dt, c->vel[c->vin],
                     c->vel[c->vin ^ 1], c->halo_flag);
   c->vin ^= 1;
 }
@@ -159,15 +172,17 @@ bool use_tb(const fluid_ctx *c, int cols) {
   return !(c->prm.flags & FLUID_FLAG_UNFUSED) && tb_supported(c->g.n, cols);
 }
 
-// simulateDiffusion()  kernel.cu:582-602
-void enq_diffuse(fluid_ctx *c) {
+// simulateDiffusion()  kernel.cu:582-602.  out_m: margin the final iterate must cover; a
+// sweep with `left` sweeps still to come must cover out_m + left.
+void enq_diffuse(fluid_ctx *c, int out_m) {
   const double cells = (double)cells_owned(c);
   if (use_tb(c, c->tb_cd)) {
     for (int left = c->prm.diffusion_iters; left > 0;) {
       const int k = next_pass(left, c->tb_kd);
       ProfScope p(c, K_DIFFUSE_TB, 16.0 * k * cells);
-      launch_diffuse_tb(c->stream, c->g, c->own_r0, c->own_r0 + c->rows, k, c->tb_cd,
-                        tb_chunk(c, k, c->tb_cd, c->rows), c->alpha, c->beta, c->vel[c->vin],
+      const Range r = widened(c, out_m + left - k);
+      launch_diffuse_tb(c->stream, c->g, r.r0, r.r1, k, c->tb_cd,
+                        tb_chunk(c, k, c->tb_cd, r.r1 - r.r0), c->alpha, c->beta, c->vel[c->vin],
                         c->vel[c->vin ^ 1]);
       c->vin ^= 1;
       left -= k;
@@ -178,8 +193,9 @@ void enq_diffuse(fluid_ctx *c) {
   }
   for (int i = 0; i < c->prm.diffusion_iters; ++i) {
     ProfScope p(c, K_DIFFUSE, 16.0 * cells);
-    launch_diffuse(c->stream, c->g, c->own_r0, c->own_r0 + c->rows, c->alpha, c->beta,
-                   c->vel[c->vin], c->vel[c->vin ^ 1]);
+    const Range r = widened(c, out_m + c->prm.diffusion_iters - 1 - i);
+    launch_diffuse(c->stream, c->g, r.r0, r.r1, c->alpha, c->beta, c->vel[c->vin],
+                   c->vel[c->vin ^ 1]);
     c->vin ^= 1;
   }
 }
@@ -198,36 +214,41 @@ void enq_vorticity(fluid_ctx *c) {
   }
 }
 
-// projection()  kernel.cu:604-662
+// projection()  kernel.cu:604-662.  The projected velocity is produced on the owned rows;
+// it needs p^J one row beyond, hence p^j on 1 + J - j rows beyond and the divergence on J.
 void enq_project(fluid_ctx *c) {
   const double cells = (double)cells_owned(c);
-  const int r0 = c->own_r0, r1 = c->own_r0 + c->rows;
+  const int J = c->prm.pressure_iters;
   {
     ProfScope p(c, K_DIVERGENCE, 12.0 * cells);
-    launch_divergence(c->stream, c->g, r0, r1, c->vel[c->vin], c->div);
+    const Range r = widened(c, J);
+    launch_divergence(c->stream, c->g, r.r0, r.r1, c->vel[c->vin], c->div);
   }
   // resetPressure()  kernel.cu:530-540: only the pressure clear is live (the
   // other two targets are overwritten before they are read).
   (void)hipMemsetAsync(c->prs[c->pin], 0, cells_local(c) * sizeof(float), c->stream);
   if (use_tb(c, c->tb_cj)) {
-    for (int left = c->prm.pressure_iters; left > 0;) {
+    for (int left = J; left > 0;) {
       const int k = next_pass(left, c->tb_kj);
       ProfScope p(c, K_JACOBI_TB, 12.0 * k * cells);
-      launch_jacobi_tb(c->stream, c->g, r0, r1, k, c->tb_cj, tb_chunk(c, k, c->tb_cj, c->rows),
+      const Range r = widened(c, 1 + left - k);
+      launch_jacobi_tb(c->stream, c->g, r.r0, r.r1, k, c->tb_cj, tb_chunk(c, k, c->tb_cj, r.r1 - r.r0),
                        c->prs[c->pin], c->div, c->prs[c->pin ^ 1]);
       c->pin ^= 1;
       left -= k;
     }
   } else {
-    for (int i = 0; i < c->prm.pressure_iters; ++i) {
+    for (int i = 0; i < J; ++i) {
       ProfScope p(c, K_JACOBI, 12.0 * cells);
-      launch_jacobi(c->stream, c->g, r0, r1, c->prs[c->pin], c->div, c->prs[c->pin ^ 1]);
+      const Range r = widened(c, J - i);
+      launch_jacobi(c->stream, c->g, r.r0, r.r1, c->prs[c->pin], c->div, c->prs[c->pin ^ 1]);
       c->pin ^= 1;
     }
   }
   {
     ProfScope p(c, K_PROJECT, 20.0 * cells);
-    launch_project(c->stream, c->g, r0, r1, c->vel[c->vin], c->prs[c->pin], c->vel[c->vin ^ 1]);
+    const Range r = widened(c, 0);
+    launch_project(c->stream, c->g, r.r0, r.r1, c->vel[c->vin], c->prs[c->pin], c->vel[c->vin ^ 1]);
     c->vin ^= 1;
   }
 }
@@ -236,15 +257,19 @@ void enq_project(fluid_ctx *c) {
 void enq_advect_density(fluid_ctx *c) {
   const double cells = (double)cells_owned(c);
   ProfScope p(c, K_ADVECT_DENS, 40.0 * cells);
-  launch_advect_dens(c->stream, c->g, c->own_r0, c->own_r0 + c->rows, c->prm.dt, c->vel[c->vin],
+  const Range r = widened(c, 0);
+  const Range valid = c->slab ? widened(c, c->halo_dens) : Range{0, c->g.L};  // density halo is A rows
+  launch_advect_dens(c->stream, c->g, r.r0, r.r1, valid.r0, valid.r1, c->prm.dt, c->vel[c->vin],
                      c->dens[c->din], c->dens[c->din ^ 1], c->halo_flag);
   c->din ^= 1;
 }
 
 // simulationStep()  kernel.cu:701-708
 void enq_step(fluid_ctx *c) {
-  enq_advect_velocity(c);
-  enq_diffuse(c);
+  // margins of the dependency cone (zero-width for whole-domain contexts, see widened())
+  const int m_diff = c->prm.pressure_iters + 1;  // diffused velocity feeds divergence on J rows
+  enq_advect_velocity(c, m_diff + c->prm.diffusion_iters);
+  enq_diffuse(c, m_diff);
   if (c->prm.flags & FLUID_FLAG_VORTICITY) enq_vorticity(c);  // kernel.cu:705
   enq_project(c);
   enq_advect_density(c);
@@ -292,6 +317,15 @@ int ensure_vort(fluid_ctx *c) {
   return FLUID_OK;
 }
 
+// After the stream has drained: did an advection gather leave the rows it may read?
+int check_halo_flag(fluid_ctx *c) {
+  if (!c->slab) return FLUID_OK;
+  int flag = 0;
+  HIPCHK(c, hipMemcpy(&flag, c->halo_flag, sizeof flag, hipMemcpyDeviceToHost));
+  if (flag) return fail(c, FLUID_E_HALO, "a backtrace was longer than halo_rows=%d rows", c->halo_dens);
+  return FLUID_OK;
+}
+
 void *field_ptr(fluid_ctx *c, int field, size_t *elem) {
   switch (field) {
     case FLUID_VELOCITY: *elem = sizeof(float2); return c->vel[c->vin];
@@ -319,23 +353,59 @@ int fluid_default_params(fluid_params *p) {
   return FLUID_OK;
 }
 
+int fluid_slab_plan(const fluid_params *p, fluid_slab_info *out) {
+  if (!p || !out) return FLUID_E_INVALID;
+  if (p->n < 4 || p->diffusion_iters < 0 || p->pressure_iters < 0) return FLUID_E_INVALID;
+  memset(out, 0, sizeof *out);
+  out->n = p->n;
+  if (p->slab_count <= 1) {
+    out->rows = p->n;
+    out->store_rows = p->n;
+    return FLUID_OK;
+  }
+  if (p->slab_rank < 0 || p->slab_rank >= p->slab_count) return FLUID_E_INVALID;
+  const int a = p->halo_rows > 0 ? p->halo_rows : 8;
+  out->row0 = (int)((long long)p->n * p->slab_rank / p->slab_count);
+  const int row1 = (int)((long long)p->n * (p->slab_rank + 1) / p->slab_count);
+  out->rows = row1 - out->row0;
+  out->halo_dens = a;
+  out->halo_vel = p->pressure_iters + 1 + p->diffusion_iters + a;
+  out->has_lo = p->slab_rank > 0;
+  out->has_hi = p->slab_rank < p->slab_count - 1;
+  // a halo must come from the adjacent slab alone, and the y-border rules read two rows inward
+  const int min_rows = p->n / p->slab_count;  // the shortest slab
+  if (min_rows < out->halo_vel || min_rows < 4) return FLUID_E_UNSUPPORTED;
+  const int lo = out->has_lo ? out->halo_vel : 0, hi = out->has_hi ? out->halo_vel : 0;
+  out->store_row0 = out->row0 - lo;
+  out->store_rows = out->rows + lo + hi;
+  return FLUID_OK;
+}
+
 int fluid_init(fluid_ctx **out, const fluid_params *p) {
   if (!out) return FLUID_E_INVALID;
   *out = nullptr;
   fluid_params prm;
   if (p) prm = *p; else fluid_default_params(&prm);
   if (prm.n < 4 || prm.diffusion_iters < 0 || prm.pressure_iters < 0) return FLUID_E_INVALID;
-  if (prm.slab_count > 1) return FLUID_E_UNSUPPORTED;
+  fluid_slab_info si;
+  int prc = fluid_slab_plan(&prm, &si);
+  if (prc) return prc;
+  if (prm.slab_count > 1 && (prm.flags & FLUID_FLAG_VORTICITY)) return FLUID_E_UNSUPPORTED;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return FLUID_E_DEVICE;  // no CPU fallback
   if (prm.device < 0 || prm.device >= ndev) return FLUID_E_INVALID;
   fluid_ctx *c = new (std::nothrow) fluid_ctx();
   if (!c) return FLUID_E_NOMEM;
   c->prm = prm;
-  c->g = Geom{prm.n, 0, prm.n};
-  c->row0 = 0;
-  c->rows = prm.n;
-  c->own_r0 = 0;
+  c->g = Geom{prm.n, si.store_row0, si.store_rows};
+  c->row0 = si.row0;
+  c->rows = si.rows;
+  c->own_r0 = si.row0 - si.store_row0;
+  c->slab = prm.slab_count > 1;
+  c->halo_vel = si.halo_vel;
+  c->halo_dens = si.halo_dens;
+  c->has_lo = si.has_lo;
+  c->has_hi = si.has_hi;
   // tuning knobs (defaults chosen from measurements); results do not depend on them
   c->tb_kj = env_int("FLUID_TB_KJ", c->tb_kj);
   c->tb_kd = env_int("FLUID_TB_KD", c->tb_kd);
@@ -418,23 +488,27 @@ int fluid_add_source(fluid_ctx *c, float sx, float sy, float fx, float fy, const
 
 int fluid_step(fluid_ctx *c, int nsteps) {
   if (!c || nsteps < 0) return FLUID_E_INVALID;
+  if (c->slab && nsteps > 1) return FLUID_E_UNSUPPORTED;  // halos must be refreshed before every step
   HIPCHK(c, hipSetDevice(c->prm.device));
   return run_steps(c, nsteps);
 }
 
-#define STAGE_FN(name, enq, pre)                \
-  int name(fluid_ctx *c) {                      \
-    if (!c) return FLUID_E_INVALID;             \
-    HIPCHK(c, hipSetDevice(c->prm.device));     \
-    pre;                                        \
-    enq(c);                                     \
-    return check_launch(c);                     \
+// Single stages are whole-domain only: in a slab the row range a stage must cover depends on
+// what follows it in the step.
+#define STAGE_FN(name, call, pre)                          \
+  int name(fluid_ctx *c) {                                 \
+    if (!c) return FLUID_E_INVALID;                        \
+    if (c->slab) return FLUID_E_UNSUPPORTED;               \
+    HIPCHK(c, hipSetDevice(c->prm.device));                \
+    pre;                                                   \
+    call;                                                  \
+    return check_launch(c);                                \
   }
-STAGE_FN(fluid_advect_velocity, enq_advect_velocity, (void)0)
-STAGE_FN(fluid_diffuse, enq_diffuse, (void)0)
-STAGE_FN(fluid_vorticity, enq_vorticity, { int r_ = ensure_vort(c); if (r_) return r_; })
-STAGE_FN(fluid_project, enq_project, (void)0)
-STAGE_FN(fluid_advect_density, enq_advect_density, (void)0)
+STAGE_FN(fluid_advect_velocity, enq_advect_velocity(c, 0), (void)0)
+STAGE_FN(fluid_diffuse, enq_diffuse(c, 0), (void)0)
+STAGE_FN(fluid_vorticity, enq_vorticity(c), { int r_ = ensure_vort(c); if (r_) return r_; })
+STAGE_FN(fluid_project, enq_project(c), (void)0)
+STAGE_FN(fluid_advect_density, enq_advect_density(c), (void)0)
 
 int fluid_read(fluid_ctx *c, int field, void *dst, size_t dst_bytes) {
   if (!c || !dst) return FLUID_E_INVALID;
@@ -452,7 +526,7 @@ int fluid_read(fluid_ctx *c, int field, void *dst, size_t dst_bytes) {
   src += (size_t)c->own_r0 * c->g.n * elem;
   HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  return FLUID_OK;
+  return check_halo_flag(c);
 }
 
 int fluid_write(fluid_ctx *c, int field, const void *srcv, size_t src_bytes) {
@@ -477,7 +551,7 @@ int fluid_sync(fluid_ctx *c) {
   if (!c) return FLUID_E_INVALID;
   HIPCHK(c, hipSetDevice(c->prm.device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  return FLUID_OK;
+  return check_halo_flag(c);
 }
 
 int fluid_geometry(const fluid_ctx *c, int *n, int *row0, int *rows) {
@@ -506,6 +580,7 @@ const char *fluid_last_error(const fluid_ctx *c) { return c ? c->err : ""; }
 
 int fluid_time_steps(fluid_ctx *c, int nsteps, float *ms_out) {
   if (!c || nsteps < 0 || !ms_out) return FLUID_E_INVALID;
+  if (c->slab && nsteps > 1) return FLUID_E_UNSUPPORTED;
   HIPCHK(c, hipSetDevice(c->prm.device));
   hipEvent_t e0, e1;
   HIPCHK(c, hipEventCreate(&e0));
@@ -527,6 +602,7 @@ int fluid_time_steps(fluid_ctx *c, int nsteps, float *ms_out) {
 int fluid_profile_steps(fluid_ctx *c, int nsteps, fluid_kernel_stat *stats, int max_stats,
                         int *count) {
   if (!c || nsteps < 0 || !stats || !count || max_stats <= 0) return FLUID_E_INVALID;
+  if (c->slab && nsteps > 1) return FLUID_E_UNSUPPORTED;
   HIPCHK(c, hipSetDevice(c->prm.device));
   c->prof = true;
   c->ev_used = 0;
@@ -553,6 +629,43 @@ int fluid_profile_steps(fluid_ctx *c, int nsteps, fluid_kernel_stat *stats, int 
     stats[k++] = acc[i];
   }
   *count = k;
+  return FLUID_OK;
+}
+
+size_t fluid_halo_bytes(const fluid_ctx *c, int dir) {
+  if (!c || !c->slab) return 0;
+  if ((dir < 0 && !c->has_lo) || (dir > 0 && !c->has_hi) || dir == 0) return 0;
+  return (size_t)c->g.n * ((size_t)c->halo_vel * sizeof(float2) + (size_t)c->halo_dens * sizeof(float4));
+}
+
+// Message layout: [halo_vel rows of float2][halo_dens rows of float4], rows in ascending y.
+int fluid_halo_pack(fluid_ctx *c, int dir, void *dst) {
+  if (!c || !dst) return FLUID_E_INVALID;
+  if (!fluid_halo_bytes(c, dir)) return FLUID_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->prm.device));
+  const size_t n = c->g.n;
+  const size_t vb = (size_t)c->halo_vel * n * sizeof(float2), db = (size_t)c->halo_dens * n * sizeof(float4);
+  // the owned rows adjacent to that neighbour
+  const size_t rv = dir < 0 ? c->own_r0 : c->own_r0 + c->rows - c->halo_vel;
+  const size_t rd = dir < 0 ? c->own_r0 : c->own_r0 + c->rows - c->halo_dens;
+  HIPCHK(c, hipMemcpyAsync(dst, c->vel[c->vin] + rv * n, vb, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync((char *)dst + vb, c->dens[c->din] + rd * n, db, hipMemcpyDeviceToDevice,
+                           c->stream));
+  return FLUID_OK;
+}
+
+int fluid_halo_unpack(fluid_ctx *c, int dir, const void *src) {
+  if (!c || !src) return FLUID_E_INVALID;
+  if (!fluid_halo_bytes(c, dir)) return FLUID_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->prm.device));
+  const size_t n = c->g.n;
+  const size_t vb = (size_t)c->halo_vel * n * sizeof(float2), db = (size_t)c->halo_dens * n * sizeof(float4);
+  // the halo rows just outside the owned rows on that side
+  const size_t rv = dir < 0 ? c->own_r0 - c->halo_vel : c->own_r0 + c->rows;
+  const size_t rd = dir < 0 ? c->own_r0 - c->halo_dens : c->own_r0 + c->rows;
+  HIPCHK(c, hipMemcpyAsync(c->vel[c->vin] + rv * n, src, vb, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->dens[c->din] + rd * n, (const char *)src + vb, db,
+                           hipMemcpyDeviceToDevice, c->stream));
   return FLUID_OK;
 }
 

@@ -33,8 +33,10 @@ extern const char *const kKernelNames[K_COUNT];
 // ---- straight (one launch per reference launch) kernels ---------------------
 // All take local row range [r0, r1) to compute; reads reach one row beyond
 // (stencils) or up to the advection halo (gathers).
-void launch_advect_vel(hipStream_t s, Geom g, int r0, int r1, float dt, const float2 *vin,
-                       float2 *vout, int *halo_flag);
+// [vlo, vhi): local rows of the gathered field that hold current data; a
+// backtrace outside raises *halo_flag.
+void launch_advect_vel(hipStream_t s, Geom g, int r0, int r1, int vlo, int vhi, float dt,
+                       const float2 *vin, float2 *vout, int *halo_flag);
 void launch_diffuse(hipStream_t s, Geom g, int r0, int r1, float alpha, float beta,
                     const float2 *vin, float2 *vout);
 void launch_divergence(hipStream_t s, Geom g, int r0, int r1, const float2 *vel, float *div);
@@ -42,8 +44,8 @@ void launch_jacobi(hipStream_t s, Geom g, int r0, int r1, const float *pin, cons
                    float *pout);
 void launch_project(hipStream_t s, Geom g, int r0, int r1, const float2 *vin, const float *p,
                     float2 *vout);
-void launch_advect_dens(hipStream_t s, Geom g, int r0, int r1, float dt, const float2 *vel,
-                        const float4 *din, float4 *dout, int *halo_flag);
+void launch_advect_dens(hipStream_t s, Geom g, int r0, int r1, int vlo, int vhi, float dt,
+                        const float2 *vel, const float4 *din, float4 *dout, int *halo_flag);
 void launch_add_force(hipStream_t s, Geom g, int r0, int r1, float dt, float radius, float sx,
                       float sy, float fx, float fy, float4 rgba, float2 *vel, float4 *dens);
 void launch_vorticity(hipStream_t s, Geom g, int r0, int r1, const float2 *vel, float *vort);

@@ -39,11 +39,13 @@ __device__ __forceinline__ float4 mix(float4 x, float4 y, float a) {
 // Clamp-to-edge texel fetch in GLOBAL coordinates from a local (slab) buffer.
 // A row outside the stored rows raises *flag (advection left the halo) and is
 // clamped so the access stays in bounds.
+struct Valid { int lo, hi; };  // local rows [lo, hi) that hold current data
+
 template <typename T>
-__device__ __forceinline__ T texel(const T *t, Geom g, int i, int j, int *flag) {
+__device__ __forceinline__ T texel(const T *t, Geom g, int i, int j, Valid v, int *flag) {
   i = clampi(i, 0, g.n - 1);
   int r = clampi(j, 0, g.n - 1) - g.ybase;
-  if (r < 0 || r >= g.L) {
+  if (r < v.lo || r >= v.hi) {
     if (flag) *flag = 1;
     r = clampi(r, 0, g.L - 1);
   }
@@ -52,18 +54,19 @@ __device__ __forceinline__ T texel(const T *t, Geom g, int i, int j, int *flag) 
 
 // LINEAR fetch at texture coordinate (bx + .5, by + .5): SURVEY.md Appendix B.2.
 template <typename T>
-__device__ __forceinline__ T bilinear(const T *t, Geom g, float bx, float by, int *flag) {
+__device__ __forceinline__ T bilinear(const T *t, Geom g, float bx, float by, Valid v, int *flag) {
   float fi = floorf(bx), fj = floorf(by);
   float a = bx - fi, b = by - fj;
   int i = (int)fi, j = (int)fj;
-  T v0 = mix(texel(t, g, i, j, flag), texel(t, g, i + 1, j, flag), a);
-  T v1 = mix(texel(t, g, i, j + 1, flag), texel(t, g, i + 1, j + 1, flag), a);
+  T v0 = mix(texel(t, g, i, j, v, flag), texel(t, g, i + 1, j, v, flag), a);
+  T v1 = mix(texel(t, g, i, j + 1, v, flag), texel(t, g, i + 1, j + 1, v, flag), a);
   return mix(v0, v1, b);
 }
 // LINEAR fetch at INTEGER texture coordinates: Appendix B.3 (2x2 mean).
 __device__ __forceinline__ float2 linear_at_int(const float2 *t, Geom g, int m, int k) {
-  float2 v0 = mix(texel(t, g, m - 1, k - 1, nullptr), texel(t, g, m, k - 1, nullptr), 0.5f);
-  float2 v1 = mix(texel(t, g, m - 1, k, nullptr), texel(t, g, m, k, nullptr), 0.5f);
+  const Valid all{0, g.L};  // border rules reach at most two rows inward of a domain edge
+  float2 v0 = mix(texel(t, g, m - 1, k - 1, all, nullptr), texel(t, g, m, k - 1, all, nullptr), 0.5f);
+  float2 v1 = mix(texel(t, g, m - 1, k, all, nullptr), texel(t, g, m, k, all, nullptr), 0.5f);
   return mix(v0, v1, 0.5f);
 }
 
@@ -76,7 +79,7 @@ __device__ __forceinline__ float2 linear_at_int(const float2 *t, Geom g, int m, 
   const bool interior = x > 0 && x < g.n - 1 && y > 0 && y < g.n - 1;
 
 // kernel.cu:114-140
-__global__ __launch_bounds__(BX *BY) void k_advect_vel(Geom g, int r0, int r1, float dt,
+__global__ __launch_bounds__(BX *BY) void k_advect_vel(Geom g, int r0, int r1, Valid valid, float dt,
                                                         const float2 *__restrict__ vin,
                                                         float2 *__restrict__ vout, int *flag) {
   CELL_PROLOGUE
@@ -86,7 +89,7 @@ __global__ __launch_bounds__(BX *BY) void k_advect_vel(Geom g, int r0, int r1, f
     float py = (float)y - dt * v.y;
     px = fmaxf(0.0f, fminf(px, (float)g.n));
     py = fmaxf(0.0f, fminf(py, (float)g.n));
-    vout[id] = bilinear(vin, g, px, py, flag);
+    vout[id] = bilinear(vin, g, px, py, valid, flag);
   } else {
     float2 o = make_float2(0.0f, 0.0f);
     if (x == 0) o = neg(linear_at_int(vin, g, x + 1, y));
@@ -98,7 +101,7 @@ __global__ __launch_bounds__(BX *BY) void k_advect_vel(Geom g, int r0, int r1, f
 }
 
 // kernel.cu:142-165
-__global__ __launch_bounds__(BX *BY) void k_advect_dens(Geom g, int r0, int r1, float dt,
+__global__ __launch_bounds__(BX *BY) void k_advect_dens(Geom g, int r0, int r1, Valid valid, float dt,
                                                          const float2 *__restrict__ vel,
                                                          const float4 *__restrict__ din,
                                                          float4 *__restrict__ dout, int *flag) {
@@ -109,7 +112,7 @@ __global__ __launch_bounds__(BX *BY) void k_advect_dens(Geom g, int r0, int r1, 
     float py = (float)y - dt * v.y;
     px = fmaxf(0.0f, fminf(px, (float)g.n));
     py = fmaxf(0.0f, fminf(py, (float)g.n));
-    dout[id] = bilinear(din, g, px, py, flag);
+    dout[id] = bilinear(din, g, px, py, valid, flag);
   } else {
     dout[id] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   }
@@ -240,10 +243,11 @@ const dim3 kBlock(BX, BY);
 
 }  // namespace
 
-void launch_advect_vel(hipStream_t s, Geom g, int r0, int r1, float dt, const float2 *vin,
-                       float2 *vout, int *flag) {
+void launch_advect_vel(hipStream_t s, Geom g, int r0, int r1, int vlo, int vhi, float dt,
+                       const float2 *vin, float2 *vout, int *flag) {
   if (r1 <= r0) return;
-  hipLaunchKernelGGL(k_advect_vel, grid_for(g, r0, r1), kBlock, 0, s, g, r0, r1, dt, vin, vout, flag);
+  hipLaunchKernelGGL(k_advect_vel, grid_for(g, r0, r1), kBlock, 0, s, g, r0, r1, Valid{vlo, vhi}, dt,
+                     vin, vout, flag);
 }
 void launch_diffuse(hipStream_t s, Geom g, int r0, int r1, float alpha, float beta,
                     const float2 *vin, float2 *vout) {
@@ -264,11 +268,11 @@ void launch_project(hipStream_t s, Geom g, int r0, int r1, const float2 *vin, co
   if (r1 <= r0) return;
   hipLaunchKernelGGL(k_project, grid_for(g, r0, r1), kBlock, 0, s, g, r0, r1, vin, p, vout);
 }
-void launch_advect_dens(hipStream_t s, Geom g, int r0, int r1, float dt, const float2 *vel,
-                        const float4 *din, float4 *dout, int *flag) {
+void launch_advect_dens(hipStream_t s, Geom g, int r0, int r1, int vlo, int vhi, float dt,
+                        const float2 *vel, const float4 *din, float4 *dout, int *flag) {
   if (r1 <= r0) return;
-  hipLaunchKernelGGL(k_advect_dens, grid_for(g, r0, r1), kBlock, 0, s, g, r0, r1, dt, vel, din, dout,
-                     flag);
+  hipLaunchKernelGGL(k_advect_dens, grid_for(g, r0, r1), kBlock, 0, s, g, r0, r1, Valid{vlo, vhi}, dt,
+                     vel, din, dout, flag);
 }
 void launch_add_force(hipStream_t s, Geom g, int r0, int r1, float dt, float radius, float sx,
                       float sy, float fx, float fy, float4 rgba, float2 *vel, float4 *dens) {

@@ -147,8 +147,10 @@ template <int C> struct JacobiOp {
     R o;
     if (YCHK && (r <= 0 || r >= N - 1)) {  // wave-uniform
 #pragma unroll
-      for (int c = 0; c < C; ++c)  // y == 0: -p[x,1]; y == N-1: -p[x,N-2]  (kernel.cu:321-322)
-        o.v[c] = neg_opaque(r <= 0 ? n.v[c] : a.v[c]);
+      for (int c = 0; c < C; ++c) {  // y == 0: -p[x,1]; y == N-1: -p[x,N-2]  (kernel.cu:321-322)
+        const float nv = n.v[c], av = a.v[c];  // values, not a select of addresses (keeps SROA)
+        o.v[c] = neg_opaque(r <= 0 ? nv : av);
+      }
       return o;
     }
     const float lft = from_left(b.v[C - 1]);

@@ -73,8 +73,8 @@ enum {
  * Slab decomposition (one process per GPU): the n x n domain is cut into
  * slab_count row slabs; this context owns rows [n*slab_rank/slab_count,
  * n*(slab_rank+1)/slab_count).  slab_count <= 1 means the whole domain.
- * Halo rows travel either through RCCL inside the library (fluid_comm_init_rccl)
- * or through the caller (fluid_halo_* below).
+ * Halo rows travel through the caller (fluid_halo_* below): one exchange per
+ * step, see fluid_slab_plan.
  */
 typedef struct fluid_params {
   int n;
@@ -87,7 +87,7 @@ typedef struct fluid_params {
   unsigned flags;      /* FLUID_FLAG_*                                        */
   int slab_rank;       /* 0 .. slab_count-1                                   */
   int slab_count;      /* 0 or 1 = no decomposition                           */
-  int halo_rows;       /* advection halo depth in rows (0 = library default)  */
+  int halo_rows;       /* A: advection reach in rows when slab-decomposed (0 = 8) */
   int reserved[5];     /* must be zero                                        */
 } fluid_params;
 
@@ -173,6 +173,41 @@ typedef struct fluid_kernel_stat {
  * fluid_step. */
 FLUID_API int fluid_profile_steps(fluid_ctx *ctx, int nsteps, fluid_kernel_stat *stats,
                                   int max_stats, int *count);
+
+/* ---- slab decomposition: one process per GPU, one halo exchange per step ----
+ *
+ * No counterpart in the reference (single GPU).  The step's dependency cone is
+ * covered by ONE exchange before the step: each slab receives
+ *   halo_vel  = J + 1 + D + A   rows of velocity and
+ *   halo_dens = A               rows of density
+ * from each neighbour (J = pressure_iters, D = diffusion_iters, A = halo_rows,
+ * the advection reach in rows, default 8) and recomputes the shrinking cone in
+ * its halo instead of exchanging a row per sweep (xGMI halo traffic is latency
+ * bound: SURVEY.md 8e).  Results are bit-identical to the whole-domain run.
+ * A backtrace longer than A rows raises a device flag; fluid_sync / fluid_read
+ * then return FLUID_E_HALO.
+ *
+ * Per step the caller does, on every slab:
+ *   fluid_halo_pack(ctx, -1, send_lo); fluid_halo_pack(ctx, +1, send_hi);
+ *   <move send_lo to rank-1's recv_hi, send_hi to rank+1's recv_lo>
+ *   fluid_halo_unpack(ctx, -1, recv_lo); fluid_halo_unpack(ctx, +1, recv_hi);
+ *   fluid_step(ctx, 1);
+ * Buffers are device memory of fluid_halo_bytes(ctx, dir) bytes; pack/unpack are
+ * asynchronous copies on the context's stream.  dir = -1 is the neighbour that
+ * owns the rows below (slab_rank - 1), +1 the one above.
+ */
+typedef struct fluid_slab_info {
+  int n, row0, rows;            /* owned rows [row0, row0 + rows)                  */
+  int halo_vel, halo_dens;      /* rows exchanged per neighbour per step            */
+  int store_row0, store_rows;   /* rows kept in the local buffers (owned + halos)   */
+  int has_lo, has_hi;           /* neighbour below / above exists                   */
+} fluid_slab_info;
+
+/* Pure host arithmetic (needs no GPU): the geometry fluid_init will use for p. */
+FLUID_API int fluid_slab_plan(const fluid_params *p, fluid_slab_info *out);
+FLUID_API size_t fluid_halo_bytes(const fluid_ctx *ctx, int dir);
+FLUID_API int fluid_halo_pack(fluid_ctx *ctx, int dir, void *dev_dst);
+FLUID_API int fluid_halo_unpack(fluid_ctx *ctx, int dir, const void *dev_src);
 
 /* ---- caller-provided stream ------------------------------------------------ */
 

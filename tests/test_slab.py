@@ -1,0 +1,134 @@
+"""Slab decomposition (multi-GPU path).  CPU: plan arithmetic and the torch.distributed halo
+protocol over gloo with world_size 2 and 3.  GPU: all slabs of a domain as separate contexts on
+one device must reproduce the whole-domain context bit for bit."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from util import ROOT, FIELDS, assert_bit_equal, random_state, read_all
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_slab_plan_arithmetic(pkg, hip):
+    # halo_vel = J + 1 + D + A, halo_dens = A (include/fluid.h); slabs tile the domain exactly
+    n, world, D, J, A = 1024, 8, 10, 40, 8
+    plans = [hip.slab_plan(n, r, world, diffusion_iters=D, pressure_iters=J, halo_rows=A) for r in range(world)]
+    assert plans[0]["row0"] == 0 and plans[-1]["row0"] + plans[-1]["rows"] == n
+    for a, b in zip(plans, plans[1:]):
+        assert a["row0"] + a["rows"] == b["row0"]
+    for r, p in enumerate(plans):
+        assert p["halo_vel"] == J + 1 + D + A and p["halo_dens"] == A
+        assert p["has_lo"] == (r > 0) and p["has_hi"] == (r < world - 1)
+        assert p["store_row0"] == p["row0"] - (p["halo_vel"] if r > 0 else 0)
+        assert p["store_rows"] == p["rows"] + p["halo_vel"] * (int(r > 0) + int(r < world - 1))
+    # uneven split
+    rows = [hip.slab_plan(1000, r, 3)["rows"] for r in range(3)]
+    assert sum(rows) == 1000 and max(rows) - min(rows) <= 1
+    # default advection reach
+    assert hip.slab_plan(4096, 1, 4)["halo_dens"] == 8
+    # whole domain
+    p = hip.slab_plan(512, 0, 1)
+    assert (p["row0"], p["rows"], p["halo_vel"], p["store_rows"]) == (0, 512, 0, 512)
+    # a slab shorter than its halo cannot be served by the adjacent slab alone
+    with pytest.raises(pkg.FluidError):
+        hip.slab_plan(256, 0, 8, pressure_iters=40)
+    with pytest.raises(pkg.FluidError):
+        hip.slab_plan(256, 3, 2)
+
+
+@pytest.mark.parametrize("world,n,D,J,A", [(2, 96, 4, 6, 1), (3, 120, 3, 5, 2), (2, 64, 10, 10, 1)])
+def test_halo_exchange_protocol_over_gloo(world, n, D, J, A):
+    """world_size > 1 on CPU: see tests/slab_gloo_worker.py."""
+    port = free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="1", GLOO_SOCKET_IFNAME="lo")
+        procs.append(subprocess.Popen(
+            [sys.executable, os.path.join(ROOT, "tests", "slab_gloo_worker.py"), str(n), str(D), str(J), str(A), "5"],
+            env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out)
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} failed:\n{out[-3000:]}"
+        assert f"rank {r} ok" in out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", [0, 4], ids=["fused", "unfused"])
+@pytest.mark.parametrize("count,n,D,J,A", [(2, 256, 10, 10, 1), (4, 512, 10, 40, 8), (3, 300, 3, 7, 2),
+                                           (8, 1024, 10, 40, 8)])
+def test_slabs_equal_whole_domain(pkg, hip, count, n, D, J, A, flags):
+    """K slab contexts + halo pack/unpack == one whole-domain context, bit for bit, over several
+    steps with seeded splats (A=1 makes the halo exactly as deep as the dependency cone, so any
+    off-by-one in a stage's row range shows)."""
+    import fluid_simulation_amd.slab as slab
+    whole = pkg.FluidSim(n, diffusion_iters=D, pressure_iters=J, flags=flags)
+    group = slab.LocalSlabGroup(pkg, n, count, diffusion_iters=D, pressure_iters=J, halo_rows=A, flags=flags)
+    ss_a, ss_b = pkg.SplatStream(), pkg.SplatStream()
+    for s in range(6):
+        if s % 2 == 0:
+            whole.add_source(*ss_a.splat())
+            group.add_source(*ss_b.splat())
+        whole.step(1)
+        group.step(1)
+    for f, fid in (("velocity", pkg.FIELD_VELOCITY), ("density", pkg.FIELD_DENSITY),
+                   ("pressure", pkg.FIELD_PRESSURE), ("divergence", pkg.FIELD_DIVERGENCE)):
+        assert_bit_equal(group.read(fid), whole.read(fid), f"{f} count={count}")
+    group.close()
+
+
+@pytest.mark.gpu
+def test_slabs_long_backtraces_and_halo_violation(pkg, hip):
+    """Backtraces of several rows are fine while they stay within halo_rows; one that leaves it
+    must be reported (FLUID_E_HALO), never silently wrong."""
+    import fluid_simulation_amd.slab as slab
+    n, count = 512, 4
+    vel, dens, _ = random_state(n, seed=5, vmax=60.0)  # dt*v up to 6 rows
+    whole = pkg.FluidSim(n)
+    whole.write(pkg.FIELD_VELOCITY, vel)
+    whole.write(pkg.FIELD_DENSITY, dens)
+    group = slab.LocalSlabGroup(pkg, n, count, halo_rows=8)
+    group.write(pkg.FIELD_VELOCITY, vel)
+    group.write(pkg.FIELD_DENSITY, dens)
+    whole.step(1)
+    group.step(1)
+    assert_bit_equal(group.read(pkg.FIELD_VELOCITY), whole.read(pkg.FIELD_VELOCITY), "velocity")
+    assert_bit_equal(group.read(pkg.FIELD_DENSITY), whole.read(pkg.FIELD_DENSITY), "density")
+    group.close()
+    # halo_rows = 2 is too shallow for 6-row backtraces
+    group = slab.LocalSlabGroup(pkg, n, count, halo_rows=2)
+    group.write(pkg.FIELD_VELOCITY, vel)
+    group.write(pkg.FIELD_DENSITY, dens)
+    with pytest.raises(pkg.FluidError) as ei:
+        group.step(1)
+        group.read(pkg.FIELD_VELOCITY)
+    assert ei.value.code == -6
+
+
+@pytest.mark.gpu
+def test_slab_contexts_reject_what_they_cannot_do(pkg, hip):
+    s = pkg.FluidSim(512, slab_rank=1, slab_count=4)
+    assert (s.row0, s.rows) == (128, 128)
+    with pytest.raises(pkg.FluidError):
+        s.step(2)          # halos must be refreshed before every step
+    with pytest.raises(pkg.FluidError):
+        s.diffuse()        # single stages are whole-domain only
+    assert s.halo_bytes(-1) == 512 * ((10 + 1 + 10 + 8) * 8 + 8 * 16) == s.halo_bytes(+1)
+    assert pkg.FluidSim(512, slab_rank=0, slab_count=4).halo_bytes(-1) == 0

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Reduce a gpurun_out/prof_TAG directory (rocprofv3 csv output) to one small JSON + text table.
+Usage: python tools/summarize_profile.py gpurun_out/prof_TAG profiles/TAG"""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+src, dst = sys.argv[1], sys.argv[2]
+
+
+def short(name):
+    m = re.search(r"(k_\w+)(<[^>]*>)?", name)
+    return (m.group(1) + (m.group(2) or "")) if m else name[:60]
+
+
+out = {"kernels": {}}
+# kernel trace: per-dispatch durations
+for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_trace.csv"), recursive=True):
+    agg = defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        agg[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    for k, v in agg.items():
+        v.sort()
+        out["kernels"][k] = {"calls": len(v), "avg_us": round(sum(v) / len(v), 2),
+                             "median_us": round(v[len(v) // 2], 2), "total_us": round(sum(v), 1)}
+# counters: per dispatch rows (Kernel_Name, Counter_Name, Counter_Value)
+pmc = defaultdict(lambda: defaultdict(list))
+for f in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        pmc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, ctrs in pmc.items():
+    d = out["kernels"].setdefault(k, {})
+    d["pmc_avg_per_dispatch"] = {c: round(sum(v) / len(v), 1) for c, v in sorted(ctrs.items())}
+os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
+json.dump(out, open(dst + ".json", "w"), indent=1, sort_keys=True)
+with open(dst + ".txt", "w") as fh:
+    tot = sum(v.get("total_us", 0) for v in out["kernels"].values())
+    fh.write(f"{'kernel':44s} {'calls':>6s} {'avg_us':>10s} {'total_us':>10s} {'%':>6s}\n")
+    for k, v in sorted(out["kernels"].items(), key=lambda kv: -kv[1].get("total_us", 0)):
+        if "calls" in v:
+            fh.write(f"{k:44s} {v['calls']:6d} {v['avg_us']:10.2f} {v['total_us']:10.1f} {100 * v['total_us'] / max(tot, 1e-9):6.1f}\n")
+    for k, v in sorted(out["kernels"].items()):
+        if "pmc_avg_per_dispatch" in v:
+            fh.write(f"\n[{k}] counters, mean per dispatch\n")
+            for c, x in v["pmc_avg_per_dispatch"].items():
+                fh.write(f"  {c:28s} {x:16.1f}\n")
+print(open(dst + ".txt").read())
