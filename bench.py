@@ -121,7 +121,7 @@ def main():
     flags = pkg.FLAG_UNFUSED if args.unfused else 0
     world = int(os.environ.get("WORLD_SIZE", "1"))
 
-    if args.gpus > 1 or world > 1:
+    if args.gpus > 1 or world > 1 or os.environ.get("FLUID_BENCH_FORCE_MULTI"):
         from bench_multi import run_multi  # slab-decomposed path
         return run_multi(pkg, args, n, D, J, flags)
 

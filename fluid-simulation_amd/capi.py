@@ -71,6 +71,14 @@ class FluidLib:
                 f"{path} is not built; run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(there is no CPU fallback)")
         self.path = path
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 (same SONAME
+        # as /opt/rocm's).  Whichever loads first serves both; torch cannot find its GPUs through
+        # the system copy, while this library runs on either, so let torch's load first when
+        # torch is installed (torch.distributed is this package's multi-GPU transport anyway).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         self.dll = C.CDLL(path, mode=C.RTLD_LOCAL)
         d = self.dll
         P = C.c_void_p

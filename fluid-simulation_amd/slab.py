@@ -37,6 +37,10 @@ class HaloExchanger:
         self.send_hi = mk(bytes_hi) if self.has_hi else None
         self.recv_hi = mk(bytes_hi) if self.has_hi else None
         self.bytes_per_step = (bytes_lo if self.has_lo else 0) + (bytes_hi if self.has_hi else 0)
+        # NCCL/RCCL transfers are stream-ordered after the packs; any other backend reads the
+        # buffers from the host side, so the packs must have landed first.
+        import torch.distributed as dist
+        self.host_ordered = torch.device(device).type == "cuda" and dist.get_backend(group) != "nccl"
 
     def exchange(self, pack: Callable[[int, int], None], unpack: Callable[[int, int], None]):
         import torch.distributed as dist
@@ -47,6 +51,9 @@ class HaloExchanger:
             pack(-1, self.send_lo.data_ptr())
         if self.has_hi:
             pack(+1, self.send_hi.data_ptr())
+        if self.host_ordered:
+            import torch
+            torch.cuda.current_stream().synchronize()
         if self.has_lo:
             ops.append(dist.P2POp(dist.isend, self.send_lo, self.rank - 1, self.group))
             ops.append(dist.P2POp(dist.irecv, self.recv_lo, self.rank - 1, self.group))

@@ -1,0 +1,47 @@
+"""One rank of the multi-process GPU slab test (all ranks share device 0; backend from argv).
+Runs the product's SlabSim exactly as bench.py --gpus N does and checks the gathered result
+against a whole-domain context bit for bit on rank 0."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import fluid_amd_loader  # noqa: E402
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    backend, n, J, steps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    pkg = fluid_amd_loader.load()
+    from fluid_simulation_amd.slab import SlabSim
+    sim = SlabSim(pkg, n, rank=rank, world=world, device_index=0, pressure_iters=J, halo_rows=2)
+    ss = pkg.SplatStream()
+    for s in range(steps):
+        if s % 2 == 0:
+            sim.add_source(*ss.splat())
+        sim.step(1)
+    sim.sync()
+    fields = {f: sim.gather(f) for f in (pkg.FIELD_VELOCITY, pkg.FIELD_DENSITY, pkg.FIELD_PRESSURE)}
+    if rank == 0:
+        whole = pkg.FluidSim(n, pressure_iters=J)
+        ss = pkg.SplatStream()
+        for s in range(steps):
+            if s % 2 == 0:
+                whole.add_source(*ss.splat())
+            whole.step(1)
+        for f, got in fields.items():
+            want = whole.read(f)
+            assert got.shape == want.shape
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"field {f} differs"
+    dist.barrier()
+    dist.destroy_process_group()
+    print(f"rank {rank} ok")
+
+
+if __name__ == "__main__":
+    main()

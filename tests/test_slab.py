@@ -132,3 +132,31 @@ def test_slab_contexts_reject_what_they_cannot_do(pkg, hip):
         s.diffuse()        # single stages are whole-domain only
     assert s.halo_bytes(-1) == 512 * ((10 + 1 + 10 + 8) * 8 + 8 * 16) == s.halo_bytes(+1)
     assert pkg.FluidSim(512, slab_rank=0, slab_count=4).halo_bytes(-1) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_slabsim_multiprocess_on_one_gpu(world):
+    """The bench's multi-rank driver (SlabSim: stream hand-over, pack -> P2P -> unpack -> step) with
+    one process per slab.  Only one GPU is available to tests and RCCL refuses two ranks on one
+    device, so the ranks share device 0 and the transport is gloo; the RCCL leg differs only in
+    the backend string."""
+    port = free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), GLOO_SOCKET_IFNAME="lo")
+        procs.append(subprocess.Popen(
+            [sys.executable, os.path.join(ROOT, "tests", "slab_gpu_worker.py"), "gloo", "512", "10", "6"],
+            env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out)
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} failed:\n{out[-3000:]}"
