@@ -46,11 +46,12 @@ struct fluid_ctx {
   float *vort = nullptr;                 // kernel.cu:458-459 (allocated on first use)
   int vin = 0, din = 0, pin = 0;  // inputVelocityBuffer / inputDensityBuffer / inputPressureBuffer
   int *halo_flag = nullptr;       // device word: advection left the stored rows
+  void *dump = nullptr;           // one row (n * 16 B): sink for rows a TB wave must not store
   float alpha = 0.f, beta = 0.f;  // diffusion constants, kernel.cu:182-183
   hipStream_t own_stream = nullptr, stream = nullptr;
   std::map<int, GraphEntry> graphs;
   // temporal-blocking plan (fused path): sweeps per launch, columns per lane, target waves
-  int tb_kj = 10, tb_kd = 5, tb_cj = 2, tb_cd = 2, tb_waves = 4096;
+  int tb_kj = 10, tb_kd = 5, tb_cj = 2, tb_cd = 2, tb_waves = 8192;
   bool prof = false;
   std::vector<hipEvent_t> ev_pool;
   size_t ev_used = 0;
@@ -149,12 +150,23 @@ int env_int(const char *name, int dflt) {
   return v && *v ? atoi(v) : dflt;
 }
 
-// Largest instantiated sweep count <= min(left, kmax)  (fluid_kernels_tb.hip TB_DISPATCH_K).
-int next_pass(int left, int kmax) {
-  static const int ks[] = {10, 8, 5, 4, 2, 1};
-  for (int k : ks)
-    if (k <= left && k <= kmax) return k;
-  return 1;
+// Next launch's sweep count: split `left` sweeps into the fewest launches the instantiated
+// counts (fluid_kernels_tb.hip tb_has_k) allow with none above kmax, and among those the most
+// even split (40 with kmax 14 -> 14 + 13 + 13, not 14 + 14 + 10 + 2).
+int next_pass(int left, int kmax, int cols, bool float2_field) {
+  if (left <= 1) return 1;
+  std::vector<int> cnt(left + 1, 1 << 20), big(left + 1, 0), pick(left + 1, 1);
+  cnt[0] = 0;
+  for (int j = 1; j <= left; ++j)
+    for (int k = 1; k <= kmax && k <= j; ++k) {
+      if (!tb_has_k(k, cols, float2_field)) continue;
+      const int c = cnt[j - k] + 1, m = big[j - k] > k ? big[j - k] : k;
+      if (c < cnt[j] || (c == cnt[j] && m < big[j])) { cnt[j] = c; big[j] = m; pick[j] = k; }
+    }
+  // launch the largest pass first (the order of the passes does not change the result)
+  int best = pick[left];
+  for (int j = left; j > 0; j -= pick[j]) best = pick[j] > best ? pick[j] : best;
+  return best;
 }
 
 // Rows per wave so that the launch has about tb_waves waves.
@@ -178,12 +190,12 @@ void enq_diffuse(fluid_ctx *c, int out_m) {
   const double cells = (double)cells_owned(c);
   if (use_tb(c, c->tb_cd)) {
     for (int left = c->prm.diffusion_iters; left > 0;) {
-      const int k = next_pass(left, c->tb_kd);
+      const int k = next_pass(left, c->tb_kd, c->tb_cd, true);
       ProfScope p(c, K_DIFFUSE_TB, 16.0 * k * cells);
       const Range r = widened(c, out_m + left - k);
       launch_diffuse_tb(c->stream, c->g, r.r0, r.r1, k, c->tb_cd,
                         tb_chunk(c, k, c->tb_cd, r.r1 - r.r0), c->alpha, c->beta, c->vel[c->vin],
-                        c->vel[c->vin ^ 1]);
+                        c->vel[c->vin ^ 1], c->dump);
       c->vin ^= 1;
       left -= k;
     }
@@ -229,11 +241,11 @@ void enq_project(fluid_ctx *c) {
   (void)hipMemsetAsync(c->prs[c->pin], 0, cells_local(c) * sizeof(float), c->stream);
   if (use_tb(c, c->tb_cj)) {
     for (int left = J; left > 0;) {
-      const int k = next_pass(left, c->tb_kj);
+      const int k = next_pass(left, c->tb_kj, c->tb_cj, false);
       ProfScope p(c, K_JACOBI_TB, 12.0 * k * cells);
       const Range r = widened(c, 1 + left - k);
       launch_jacobi_tb(c->stream, c->g, r.r0, r.r1, k, c->tb_cj, tb_chunk(c, k, c->tb_cj, r.r1 - r.r0),
-                       c->prs[c->pin], c->div, c->prs[c->pin ^ 1]);
+                       c->prs[c->pin], c->div, c->prs[c->pin ^ 1], c->dump);
       c->pin ^= 1;
       left -= k;
     }
@@ -408,6 +420,10 @@ int fluid_init(fluid_ctx **out, const fluid_params *p) {
   c->has_hi = si.has_hi;
   // tuning knobs (defaults chosen from measurements); results do not depend on them
   c->tb_kj = env_int("FLUID_TB_KJ", c->tb_kj);
+  // measured: two 5-sweep diffusion launches win while the fields sit in the
+  // Infinity Cache; from 8192^2 cells up one 10-sweep
+  // launch wins (HBM round trips dominate); likewise 10 vs 14 Jacobi sweeps per launch
+  if ((long long)prm.n * si.rows >= (1ll << 26)) { c->tb_kd = 10; c->tb_kj = 14; }
   c->tb_kd = env_int("FLUID_TB_KD", c->tb_kd);
   c->tb_cj = env_int("FLUID_TB_CJ", c->tb_cj);
   c->tb_cd = env_int("FLUID_TB_CD", c->tb_cd);
@@ -431,6 +447,7 @@ int fluid_init(fluid_ctx **out, const fluid_params *p) {
     }
     HIPCHK(c, hipMalloc(&c->div, nc * sizeof(float)));
     HIPCHK(c, hipMemsetAsync(c->div, 0, nc * sizeof(float), c->stream));
+    HIPCHK(c, hipMalloc(&c->dump, (size_t)prm.n * 16 + 256));
     HIPCHK(c, hipMalloc(&c->halo_flag, 256));
     HIPCHK(c, hipMemsetAsync(c->halo_flag, 0, 256, c->stream));
     if (prm.flags & FLUID_FLAG_VORTICITY) {
@@ -462,6 +479,7 @@ void fluid_destroy(fluid_ctx *c) {
   if (c->div) (void)hipFree(c->div);
   if (c->vort) (void)hipFree(c->vort);
   if (c->halo_flag) (void)hipFree(c->halo_flag);
+  if (c->dump) (void)hipFree(c->dump);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }

@@ -55,9 +55,11 @@ void launch_add_vorticity(hipStream_t s, Geom g, int r0, int r1, float dt, const
 // ---- temporally blocked sweeps (fluid_kernels_tb.hip) -----------------------
 // k sweeps per launch; cols = columns per lane (2 or 4); chunk = rows a wave
 // streams.  Return false when the shape is unsupported (caller falls back to
-// the straight kernels): n % cols != 0 or k not instantiated.
+// the straight kernels): n % cols != 0 or k not instantiated.  dump: one row of
+// n * 16 bytes of device memory that receives the rows a wave computes but must not store.
 bool tb_supported(int n, int cols);
+bool tb_has_k(int k, int cols, bool float2_field);
 bool launch_jacobi_tb(hipStream_t s, Geom g, int r0, int r1, int k, int cols, int chunk,
-                      const float *pin, const float *div, float *pout);
+                      const float *pin, const float *div, float *pout, void *dump);
 bool launch_diffuse_tb(hipStream_t s, Geom g, int r0, int r1, int k, int cols, int chunk,
-                       float alpha, float beta, const float2 *vin, float2 *vout);
+                       float alpha, float beta, const float2 *vin, float2 *vout, void *dump);

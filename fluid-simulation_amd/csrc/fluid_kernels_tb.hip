@@ -134,12 +134,14 @@ template <int C> struct JacobiOp {
   using R = Row<C>;
   using A = Row<C>;  // divergence row
   using Elem = float;
-  struct P { const float *in; const float *aux; float *out; };
+  struct P { const float *in; const float *aux; float *out; float *dump; };
   static __device__ __forceinline__ R zero() { return zero_row<C>(); }
   static __device__ __forceinline__ A zero_aux() { return zero_row<C>(); }
   static __device__ __forceinline__ R load(const P &p, size_t off) { return load_row<C>(p.in + off); }
   static __device__ __forceinline__ A load_aux(const P &p, size_t off) { return load_row<C>(p.aux + off); }
-  static __device__ __forceinline__ void store(const P &p, size_t off, const R &r) { store_row<C>(p.out + off, r); }
+  static __device__ __forceinline__ void store(const P &p, bool real, size_t off, size_t doff, const R &r) {
+    store_row<C>(real ? p.out + off : p.dump + doff, r);
+  }
 
   template <bool XEDGE, bool YCHK>
   static __device__ __forceinline__ R apply(const R &a, const R &b, const R &n, const A &d, int r,
@@ -175,12 +177,14 @@ template <int C> struct JacobiOp {
 template <int C> struct DiffuseOp {
   using R = Row2<C>;
   using A = NoAux;
-  struct P { const float2 *in; float2 *out; float alpha, beta; };
+  struct P { const float2 *in; float2 *out; float2 *dump; float alpha, beta; };
   static __device__ __forceinline__ R zero() { return zero_row2<C>(); }
   static __device__ __forceinline__ A zero_aux() { return NoAux{}; }
   static __device__ __forceinline__ R load(const P &p, size_t off) { return load_row2<C>(p.in + off); }
   static __device__ __forceinline__ A load_aux(const P &, size_t) { return NoAux{}; }
-  static __device__ __forceinline__ void store(const P &p, size_t off, const R &r) { store_row2<C>(p.out + off, r); }
+  static __device__ __forceinline__ void store(const P &p, bool real, size_t off, size_t doff, const R &r) {
+    store_row2<C>(real ? p.out + off : p.dump + doff, r);
+  }
 
   template <bool XEDGE, bool YCHK>
   static __device__ __forceinline__ R apply(const R &a, const R &b, const R &n, const A &, int r,
@@ -220,19 +224,26 @@ template <class Op, int K, bool XEDGE> struct Pipe {
   using A = typename Op::A;
   using P = typename Op::P;
   R s[K + 1][3];
-  A dv[K];          // dv[l] = aux row needed by level l+1 this step (row t-l-1)
-  R q0, q1;         // prefetched level-0 rows t, t+1
-  A dq0, dq1, dprev;  // aux rows t, t+1, t-1
+  A dv[K];   // dv[l] = aux row needed by level l+1 this step (row t-l-1)
+  R pf[3];   // prefetch ring: in phase J, pf[J] = level-0 row t, pf[J+1] = row t+1, pf[J+2] = row t+2 (loading)
+  A apf[3];  // aux ring: apf[J] = row t, apf[J+1] = row t+1, apf[J+2] = row t-1, then reloaded with row t+2
   Geom g;
-  int x0, ya, yb;
-  bool in_dom, st_ok;
+  int x0, xc, ya, yb;  // xc: x0 clamped into the domain (address of this lane's loads)
+  bool st_ok;
 
-  __device__ __forceinline__ bool row_ok(int t) const {
-    return in_dom && t >= 0 && t < g.n && t - g.ybase >= 0 && t - g.ybase < g.L;
+  // Every load and store below is UNCONDITIONAL.  A predicated or branched-around memory
+  // operation makes hipcc's s_waitcnt placement assume it may not have been issued, and the
+  // wait before a prefetched row degrades to vmcnt(0/1), i.e. no prefetch at all.  So rows and
+  // columns outside the stored data are read from a clamped address (the values only ever feed
+  // cells that are not stored: a strip/chunk edge loses one ring of cells per sweep, and at a
+  // domain border the boundary rule never reads outward), and rows that must not be stored go
+  // to a dump row instead of being skipped.
+  __device__ __forceinline__ size_t off(int t) const {
+    const int r = min(max(t - g.ybase, 0), g.L - 1);
+    return (size_t)r * g.n + xc;
   }
-  __device__ __forceinline__ size_t off(int t) const { return (size_t)(t - g.ybase) * g.n + x0; }
-  __device__ __forceinline__ R ld(const P &p, int t) const { return row_ok(t) ? Op::load(p, off(t)) : Op::zero(); }
-  __device__ __forceinline__ A lda(const P &p, int t) const { return row_ok(t) ? Op::load_aux(p, off(t)) : Op::zero_aux(); }
+  __device__ __forceinline__ R ld(const P &p, int t) const { return Op::load(p, off(t)); }
+  __device__ __forceinline__ A lda(const P &p, int t) const { return Op::load_aux(p, off(t)); }
 
   __device__ __forceinline__ void init(const P &p, int t0) {
 #pragma unroll
@@ -241,9 +252,9 @@ template <class Op, int K, bool XEDGE> struct Pipe {
       for (int j = 0; j < 3; ++j) s[l][j] = Op::zero();
       dv[l] = Op::zero_aux();
     }
-    dprev = Op::zero_aux();
-    q0 = ld(p, t0); dq0 = lda(p, t0);
-    q1 = ld(p, t0 + 1); dq1 = lda(p, t0 + 1);
+    pf[0] = ld(p, t0); apf[0] = lda(p, t0);
+    pf[1] = ld(p, t0 + 1); apf[1] = lda(p, t0 + 1);
+    pf[2] = Op::zero(); apf[2] = Op::zero_aux();  // "row t0-1": never feeds a stored row
   }
 
   template <int J, bool YCHK>
@@ -258,22 +269,21 @@ template <class Op, int K, bool XEDGE> struct Pipe {
     return fin;
   }
 
+  // One time step.  Nothing loop-carried changes register: the rings are indexed by the phase,
+  // so the loads issued here are first touched two steps later (counted vmcnt, not vmcnt(0)).
   template <int J>
   __device__ __forceinline__ void step(const P &p, int t) {
-    R pre = ld(p, t + 2);  // prefetch two rows ahead
-    A dpre = lda(p, t + 2);
-    s[0][(J + 2) % 3] = q0;  // level 0, row t
 #pragma unroll
     for (int l = K - 1; l > 0; --l) dv[l] = dv[l - 1];
-    dv[0] = dprev;  // aux row t-1
+    dv[0] = apf[(J + 2) % 3];          // aux row t-1 (loaded three steps ago)
+    s[0][(J + 2) % 3] = pf[J % 3];     // level 0, row t
+    pf[(J + 2) % 3] = ld(p, t + 2);    // prefetch two rows ahead into the slots just freed
+    apf[(J + 2) % 3] = lda(p, t + 2);
     R fin;
     if (t - K >= 1 && t - 1 <= g.n - 2) fin = levels<J, false>(p, t);  // every level's row is y-interior
     else fin = levels<J, true>(p, t);
     const int ro = t - K;  // level K row just produced
-    if (st_ok && ro >= ya && ro < yb) Op::store(p, off(ro), fin);
-    dprev = dq0;
-    q0 = q1; dq0 = dq1;
-    q1 = pre; dq1 = dpre;
+    Op::store(p, st_ok && ro >= ya && ro < yb, off(ro), (size_t)xc, fin);
   }
 
   __device__ __forceinline__ void run(const P &p) {
@@ -298,16 +308,17 @@ __device__ __forceinline__ void tb_kernel_body(Geom g, int r0, int r1, int chunk
   const int x0 = xs - SG::HX + lane * C;
   const bool in_dom = x0 >= 0 && x0 < g.n;  // n % C == 0: a lane's columns are all in or all out
   const bool st_ok = in_dom && lane * C >= SG::HX && lane * C < SG::HX + SG::VW;
+  const int xc = min(max(x0, 0), g.n - C);
   const int ya = g.ybase + r0 + blockIdx.y * chunk;
   const int yb = min(ya + chunk, g.ybase + r1);
   const bool xedge = xs == 0 || xs + SG::VW + SG::HX >= g.n;  // wave-uniform
   if (xedge) {
     Pipe<Op, K, true> pipe;
-    pipe.g = g; pipe.x0 = x0; pipe.ya = ya; pipe.yb = yb; pipe.in_dom = in_dom; pipe.st_ok = st_ok;
+    pipe.g = g; pipe.x0 = x0; pipe.xc = xc; pipe.ya = ya; pipe.yb = yb; pipe.st_ok = st_ok;
     pipe.run(p);
   } else {
     Pipe<Op, K, false> pipe;
-    pipe.g = g; pipe.x0 = x0; pipe.ya = ya; pipe.yb = yb; pipe.in_dom = in_dom; pipe.st_ok = st_ok;
+    pipe.g = g; pipe.x0 = x0; pipe.xc = xc; pipe.ya = ya; pipe.yb = yb; pipe.st_ok = st_ok;
     pipe.run(p);
   }
 }
@@ -315,16 +326,16 @@ __device__ __forceinline__ void tb_kernel_body(Geom g, int r0, int r1, int chunk
 template <int K, int C>
 __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK) void k_jacobi_tb(
     Geom g, int r0, int r1, int chunk, const float *__restrict__ pin,
-    const float *__restrict__ div, float *__restrict__ pout) {
-  typename JacobiOp<C>::P p{pin, div, pout};
+    const float *__restrict__ div, float *__restrict__ pout, float *__restrict__ dump) {
+  typename JacobiOp<C>::P p{pin, div, pout, dump};
   tb_kernel_body<JacobiOp<C>, K, C>(g, r0, r1, chunk, p);
 }
 
 template <int K, int C>
 __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK) void k_diffuse_tb(
     Geom g, int r0, int r1, int chunk, float alpha, float beta, const float2 *__restrict__ vin,
-    float2 *__restrict__ vout) {
-  typename DiffuseOp<C>::P p{vin, vout, alpha, beta};
+    float2 *__restrict__ vout, float2 *__restrict__ dump) {
+  typename DiffuseOp<C>::P p{vin, vout, dump, alpha, beta};
   tb_kernel_body<DiffuseOp<C>, K, C>(g, r0, r1, chunk, p);
 }
 
@@ -337,20 +348,23 @@ dim3 tb_grid(Geom g, int r0, int r1, int chunk) {
 
 template <int K, int C>
 void jacobi_tb_launch(hipStream_t s, Geom g, int r0, int r1, int chunk, const float *pin,
-                      const float *div, float *pout) {
+                      const float *div, float *pout, void *dump) {
   const dim3 grid = tb_grid<K, C>(g, r0, r1, chunk);
-  k_jacobi_tb<K, C><<<grid, dim3(WAVE * WAVES_PER_BLOCK), 0, s>>>(g, r0, r1, chunk, pin, div, pout);
+  k_jacobi_tb<K, C><<<grid, dim3(WAVE * WAVES_PER_BLOCK), 0, s>>>(g, r0, r1, chunk, pin, div, pout,
+                                                                 (float *)dump);
 }
 template <int K, int C>
 void diffuse_tb_launch(hipStream_t s, Geom g, int r0, int r1, int chunk, float alpha, float beta,
-                       const float2 *vin, float2 *vout) {
+                       const float2 *vin, float2 *vout, void *dump) {
   const dim3 grid = tb_grid<K, C>(g, r0, r1, chunk);
   k_diffuse_tb<K, C><<<grid, dim3(WAVE * WAVES_PER_BLOCK), 0, s>>>(g, r0, r1, chunk, alpha, beta, vin,
-                                                                vout);
+                                                                vout, (float2 *)dump);
 }
 
 }  // namespace
 
+// Instantiated sweep counts.  Wide lanes (4 columns) stop at 10 sweeps (VGPR budget); the
+// 2-column form goes to 20 (about 200 VGPRs, two waves per SIMD).
 #define TB_DISPATCH_K(FN, C_, ...)                    \
   switch (k) {                                        \
     case 1: FN<1, C_>(__VA_ARGS__); return true;      \
@@ -359,23 +373,50 @@ void diffuse_tb_launch(hipStream_t s, Geom g, int r0, int r1, int chunk, float a
     case 5: FN<5, C_>(__VA_ARGS__); return true;      \
     case 8: FN<8, C_>(__VA_ARGS__); return true;      \
     case 10: FN<10, C_>(__VA_ARGS__); return true;    \
-    default: return false;                            \
+    default: break;                                   \
+  }
+#define TB_DISPATCH_K_DEEP(FN, C_, ...)               \
+  switch (k) {                                        \
+    case 13: FN<13, C_>(__VA_ARGS__); return true;    \
+    case 14: FN<14, C_>(__VA_ARGS__); return true;    \
+    case 20: FN<20, C_>(__VA_ARGS__); return true;    \
+    default: break;                                   \
   }
 
 bool tb_supported(int n, int cols) { return (cols == 2 || cols == 4) && n % cols == 0 && n >= 8; }
+bool tb_has_k(int k, int cols, bool float2_field) {
+  switch (k) {
+    case 1: case 2: case 4: case 5: case 8: return true;
+    case 10: return !(float2_field && cols == 4);  // diffusion 10 x 4 columns overflows the VGPR file
+    case 13: case 14: case 20: return cols == 2 && !float2_field;
+    default: return false;
+  }
+}
 
 bool launch_jacobi_tb(hipStream_t s, Geom g, int r0, int r1, int k, int cols, int chunk,
-                      const float *pin, const float *div, float *pout) {
+                      const float *pin, const float *div, float *pout, void *dump) {
   if (r1 <= r0) return true;
-  if (!tb_supported(g.n, cols) || chunk < 1) return false;
-  if (cols == 4) { TB_DISPATCH_K(jacobi_tb_launch, 4, s, g, r0, r1, chunk, pin, div, pout) }
-  TB_DISPATCH_K(jacobi_tb_launch, 2, s, g, r0, r1, chunk, pin, div, pout)
+  if (!tb_supported(g.n, cols) || chunk < 1 || !tb_has_k(k, cols, false)) return false;
+  if (cols == 4) { TB_DISPATCH_K(jacobi_tb_launch, 4, s, g, r0, r1, chunk, pin, div, pout, dump) return false; }
+  TB_DISPATCH_K(jacobi_tb_launch, 2, s, g, r0, r1, chunk, pin, div, pout, dump)
+  TB_DISPATCH_K_DEEP(jacobi_tb_launch, 2, s, g, r0, r1, chunk, pin, div, pout, dump)
+  return false;
 }
 
 bool launch_diffuse_tb(hipStream_t s, Geom g, int r0, int r1, int k, int cols, int chunk,
-                       float alpha, float beta, const float2 *vin, float2 *vout) {
+                       float alpha, float beta, const float2 *vin, float2 *vout, void *dump) {
   if (r1 <= r0) return true;
-  if (!tb_supported(g.n, cols) || chunk < 1) return false;
-  if (cols == 4) { TB_DISPATCH_K(diffuse_tb_launch, 4, s, g, r0, r1, chunk, alpha, beta, vin, vout) }
-  TB_DISPATCH_K(diffuse_tb_launch, 2, s, g, r0, r1, chunk, alpha, beta, vin, vout)
+  if (!tb_supported(g.n, cols) || chunk < 1 || !tb_has_k(k, cols, true)) return false;
+  if (cols == 4) {
+    switch (k) {  // no K = 10 here
+      case 1: diffuse_tb_launch<1, 4>(s, g, r0, r1, chunk, alpha, beta, vin, vout, dump); return true;
+      case 2: diffuse_tb_launch<2, 4>(s, g, r0, r1, chunk, alpha, beta, vin, vout, dump); return true;
+      case 4: diffuse_tb_launch<4, 4>(s, g, r0, r1, chunk, alpha, beta, vin, vout, dump); return true;
+      case 5: diffuse_tb_launch<5, 4>(s, g, r0, r1, chunk, alpha, beta, vin, vout, dump); return true;
+      case 8: diffuse_tb_launch<8, 4>(s, g, r0, r1, chunk, alpha, beta, vin, vout, dump); return true;
+      default: return false;
+    }
+  }
+  TB_DISPATCH_K(diffuse_tb_launch, 2, s, g, r0, r1, chunk, alpha, beta, vin, vout, dump)
+  return false;
 }

@@ -17,12 +17,12 @@ which = sys.argv[3] if len(sys.argv) > 3 else "jacobi"
 steps = 3 if n > 8192 else 6
 
 if which == "jacobi":
-    grid = itertools.product((4, 5, 8, 10), (2, 4), (1024, 2048, 4096, 8192, 16384))
+    grid = [(k, c, w) for k in (8, 10, 13, 14, 20) for c in (2, 4) for w in (2048, 4096, 8192) if not (k > 10 and c == 4)]
     names = ("FLUID_TB_KJ", "FLUID_TB_CJ", "FLUID_TB_WAVES")
     kern = "k_jacobi_tb"
     total = J
 else:
-    grid = itertools.product((2, 5, 10), (2, 4), (1024, 2048, 4096, 8192, 16384))
+    grid = [(k, c, w) for k in (5, 10) for c in (2, 4) for w in (2048, 4096, 8192)]
     names = ("FLUID_TB_KD", "FLUID_TB_CD", "FLUID_TB_WAVES")
     kern = "k_diffuse_tb"
     total = 10
