@@ -231,16 +231,29 @@ void enq_vorticity(fluid_ctx *c) {
 void enq_project(fluid_ctx *c) {
   const double cells = (double)cells_owned(c);
   const int J = c->prm.pressure_iters;
-  {
-    ProfScope p(c, K_DIVERGENCE, 12.0 * cells);
-    const Range r = widened(c, J);
-    launch_divergence(c->stream, c->g, r.r0, r.r1, c->vel[c->vin], c->div);
+  const bool tb = use_tb(c, c->tb_cj);
+  int left = J;
+  if (tb && J > 0) {
+    // divergence + resetPressure (p^0 == 0 is a constant, not a buffer) + the first sweeps
+    const int k = next_pass(left, c->tb_kj, c->tb_cj, false);
+    ProfScope p(c, K_JACOBI_DIV_TB, 12.0 * cells + 12.0 * k * cells);
+    const Range r = widened(c, 1 + left - k);
+    launch_jacobi_div_tb(c->stream, c->g, r.r0, r.r1, k, c->tb_cj, tb_chunk(c, k, c->tb_cj, r.r1 - r.r0),
+                         c->vel[c->vin], c->div, c->prs[c->pin ^ 1], c->dump);
+    c->pin ^= 1;
+    left -= k;
+  } else {
+    {
+      ProfScope p(c, K_DIVERGENCE, 12.0 * cells);
+      const Range r = widened(c, J);
+      launch_divergence(c->stream, c->g, r.r0, r.r1, c->vel[c->vin], c->div);
+    }
+    // resetPressure()  kernel.cu:530-540: only the pressure clear is live (the
+    // other two targets are overwritten before they are read).
+    (void)hipMemsetAsync(c->prs[c->pin], 0, cells_local(c) * sizeof(float), c->stream);
   }
-  // resetPressure()  kernel.cu:530-540: only the pressure clear is live (the
-  // other two targets are overwritten before they are read).
-  (void)hipMemsetAsync(c->prs[c->pin], 0, cells_local(c) * sizeof(float), c->stream);
-  if (use_tb(c, c->tb_cj)) {
-    for (int left = J; left > 0;) {
+  if (tb) {
+    while (left > 0) {
       const int k = next_pass(left, c->tb_kj, c->tb_cj, false);
       ProfScope p(c, K_JACOBI_TB, 12.0 * k * cells);
       const Range r = widened(c, 1 + left - k);

@@ -25,7 +25,8 @@ enum KernelId {
   K_VORTICITY,
   K_ADD_VORTICITY,
   K_DIFFUSE_TB,   // temporally blocked diffusion
-  K_JACOBI_TB,    // temporally blocked Jacobi (optionally fused divergence prologue)
+  K_JACOBI_TB,    // temporally blocked Jacobi
+  K_JACOBI_DIV_TB,  // divergence + pressure clear + first Jacobi launch
   K_COUNT
 };
 extern const char *const kKernelNames[K_COUNT];
@@ -61,5 +62,8 @@ bool tb_supported(int n, int cols);
 bool tb_has_k(int k, int cols, bool float2_field);
 bool launch_jacobi_tb(hipStream_t s, Geom g, int r0, int r1, int k, int cols, int chunk,
                       const float *pin, const float *div, float *pout, void *dump);
+// divergence + p^0 = 0 + the first k Jacobi sweeps in one launch (writes div and p)
+bool launch_jacobi_div_tb(hipStream_t s, Geom g, int r0, int r1, int k, int cols, int chunk,
+                          const float2 *vel, float *div_out, float *pout, void *dump);
 bool launch_diffuse_tb(hipStream_t s, Geom g, int r0, int r1, int k, int cols, int chunk,
                        float alpha, float beta, const float2 *vin, float2 *vout, void *dump);

@@ -142,6 +142,22 @@ template <int C> struct JacobiOp {
   static __device__ __forceinline__ void store(const P &p, bool real, size_t off, size_t doff, const R &r) {
     store_row<C>(real ? p.out + off : p.dump + doff, r);
   }
+  static constexpr bool kLoadsField = true;  // level 0 is read from memory
+
+  // Divergence rows come from memory through a three-slot ring indexed by the phase.
+  template <bool XEDGE> struct Feed {
+    A apf[3];  // in phase J: apf[J] = row t, apf[J+1] = row t+1, apf[J+2] = row t-1 (then reloaded: t+2)
+    template <class PipeT> __device__ __forceinline__ void init(const PipeT &pp, const P &p, int t0) {
+      apf[0] = load_aux(p, pp.off(t0));
+      apf[1] = load_aux(p, pp.off(t0 + 1));
+      apf[2] = zero_aux();  // "row t0-1": never feeds a stored row
+    }
+    template <int J, class PipeT> __device__ __forceinline__ A next(const PipeT &pp, const P &p, int t) {
+      A r = apf[(J + 2) % 3];                        // row t-1 (loaded three steps ago)
+      apf[(J + 2) % 3] = load_aux(p, pp.off(t + 2));  // prefetch row t+2 into the freed slot
+      return r;
+    }
+  };
 
   template <bool XEDGE, bool YCHK>
   static __device__ __forceinline__ R apply(const R &a, const R &b, const R &n, const A &d, int r,
@@ -185,6 +201,11 @@ template <int C> struct DiffuseOp {
   static __device__ __forceinline__ void store(const P &p, bool real, size_t off, size_t doff, const R &r) {
     store_row2<C>(real ? p.out + off : p.dump + doff, r);
   }
+  static constexpr bool kLoadsField = true;
+  template <bool XEDGE> struct Feed {  // no auxiliary field
+    template <class PipeT> __device__ __forceinline__ void init(const PipeT &, const P &, int) {}
+    template <int J, class PipeT> __device__ __forceinline__ A next(const PipeT &, const P &, int) { return NoAux{}; }
+  };
 
   template <bool XEDGE, bool YCHK>
   static __device__ __forceinline__ R apply(const R &a, const R &b, const R &n, const A &, int r,
@@ -211,6 +232,74 @@ template <int C> struct DiffuseOp {
   }
 };
 
+// First projection launch: divergence (kernel.cu:265-289) + resetPressure (kernel.cu:530-540,
+// p^0 == 0 is never read from memory) + the first K pressureJacobi sweeps, in one pass over the
+// velocity.  Same sweep rule as JacobiOp; only where level 0 and the divergence come from differs:
+// level 0 is the constant 0 and divergence row t is computed from velocity rows t-1, t, t+1 as
+// they stream by (and written out for the later launches and for fluid_read).
+template <int C> struct JacobiDivOp : JacobiOp<C> {
+  using R = Row<C>;
+  using A = Row<C>;
+  struct P { const float2 *vel; float *div_out; float *out; float *dump; int n; };
+  static __device__ __forceinline__ R load(const P &, size_t) { return zero_row<C>(); }
+  static __device__ __forceinline__ void store(const P &p, bool real, size_t off, size_t doff, const R &r) {
+    store_row<C>(real ? p.out + off : p.dump + doff, r);
+  }
+  static constexpr bool kLoadsField = false;
+
+  template <bool XEDGE, bool YCHK>
+  static __device__ __forceinline__ R apply(const R &a, const R &b, const R &n, const A &d, int r,
+                                            int x0, int N, const P &) {
+    return JacobiOp<C>::template apply<XEDGE, YCHK>(a, b, n, d, r, x0, N, typename JacobiOp<C>::P{});
+  }
+
+  template <bool XEDGE> struct Feed {
+    Row2<C> vpf[3];  // velocity ring: in phase J slot J holds row t+1 (issued three steps ago)
+    Row2<C> va, vb;  // velocity rows t-1 and t
+    A dcur;          // divergence row t-1
+    template <class PipeT> __device__ __forceinline__ void init(const PipeT &pp, const P &p, int t0) {
+      va = zero_row2<C>();
+      vb = load_row2<C>(p.vel + pp.off(t0));
+      vpf[0] = load_row2<C>(p.vel + pp.off(t0 + 1));
+      vpf[1] = load_row2<C>(p.vel + pp.off(t0 + 2));
+      vpf[2] = load_row2<C>(p.vel + pp.off(t0 + 3));
+      dcur = zero_row<C>();
+    }
+    template <int J, class PipeT> __device__ __forceinline__ A next(const PipeT &pp, const P &p, int t) {
+      const A ret = dcur;                               // divergence row t-1
+      const Row2<C> vc = vpf[J % 3];                    // velocity row t+1
+      vpf[J % 3] = load_row2<C>(p.vel + pp.off(t + 4));  // prefetch three steps ahead
+      A d;
+      const int N = pp.g.n;
+      if (t <= 0 || t >= N - 1) {  // wave-uniform: border rows, kernel.cu:287
+        d = zero_row<C>();
+      } else {
+        const float lu = from_left(vb.u[C - 1]);
+        const float ru = from_right(vb.u[0]);
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          const float uL = c > 0 ? vb.u[c - 1] : lu;
+          const float uR = c < C - 1 ? vb.u[c + 1] : ru;
+          float v = 0.5f * ((uR - uL) + (vc.w[c] - va.w[c]));  // kernel.cu:282
+          if (XEDGE) {
+            const int x = pp.x0 + c;
+            if (x == 0 || x == N - 1) v = 0.0f;  // kernel.cu:287
+          }
+          d.v[c] = v;
+        }
+      }
+      // divergence row t is part of the state (later launches, fluid_read): store it for the
+      // rows and columns this wave owns, to the dump row otherwise
+      const bool real = pp.st_ok && t >= pp.ya && t < pp.yb;
+      store_row<C>(real ? p.div_out + pp.off(t) : p.dump + (size_t)p.n + pp.xc, d);
+      va = vb;
+      vb = vc;
+      dcur = d;
+      return ret;
+    }
+  };
+};
+
 // ---------------------------------------------------------------------------
 // The register pipeline.  Level l keeps three row slots s[l][0..2] used as a
 // ring: in a step of phase J the slots (J, J+1, J+2) mod 3 hold rows
@@ -226,7 +315,7 @@ template <class Op, int K, bool XEDGE> struct Pipe {
   R s[K + 1][3];
   A dv[K];   // dv[l] = aux row needed by level l+1 this step (row t-l-1)
   R pf[3];   // prefetch ring: in phase J, pf[J] = level-0 row t, pf[J+1] = row t+1, pf[J+2] = row t+2 (loading)
-  A apf[3];  // aux ring: apf[J] = row t, apf[J+1] = row t+1, apf[J+2] = row t-1, then reloaded with row t+2
+  typename Op::template Feed<XEDGE> feed;  // where the auxiliary rows come from
   Geom g;
   int x0, xc, ya, yb;  // xc: x0 clamped into the domain (address of this lane's loads)
   bool st_ok;
@@ -243,7 +332,6 @@ template <class Op, int K, bool XEDGE> struct Pipe {
     return (size_t)r * g.n + xc;
   }
   __device__ __forceinline__ R ld(const P &p, int t) const { return Op::load(p, off(t)); }
-  __device__ __forceinline__ A lda(const P &p, int t) const { return Op::load_aux(p, off(t)); }
 
   __device__ __forceinline__ void init(const P &p, int t0) {
 #pragma unroll
@@ -252,9 +340,10 @@ template <class Op, int K, bool XEDGE> struct Pipe {
       for (int j = 0; j < 3; ++j) s[l][j] = Op::zero();
       dv[l] = Op::zero_aux();
     }
-    pf[0] = ld(p, t0); apf[0] = lda(p, t0);
-    pf[1] = ld(p, t0 + 1); apf[1] = lda(p, t0 + 1);
-    pf[2] = Op::zero(); apf[2] = Op::zero_aux();  // "row t0-1": never feeds a stored row
+    pf[0] = ld(p, t0);
+    pf[1] = ld(p, t0 + 1);
+    pf[2] = Op::zero();
+    feed.init(*this, p, t0);
   }
 
   template <int J, bool YCHK>
@@ -275,10 +364,11 @@ template <class Op, int K, bool XEDGE> struct Pipe {
   __device__ __forceinline__ void step(const P &p, int t) {
 #pragma unroll
     for (int l = K - 1; l > 0; --l) dv[l] = dv[l - 1];
-    dv[0] = apf[(J + 2) % 3];          // aux row t-1 (loaded three steps ago)
-    s[0][(J + 2) % 3] = pf[J % 3];     // level 0, row t
-    pf[(J + 2) % 3] = ld(p, t + 2);    // prefetch two rows ahead into the slots just freed
-    apf[(J + 2) % 3] = lda(p, t + 2);
+    dv[0] = feed.template next<J>(*this, p, t);  // aux row t-1
+    if constexpr (Op::kLoadsField) {
+      s[0][(J + 2) % 3] = pf[J % 3];   // level 0, row t
+      pf[(J + 2) % 3] = ld(p, t + 2);  // prefetch two rows ahead into the slot just freed
+    }
     R fin;
     if (t - K >= 1 && t - 1 <= g.n - 2) fin = levels<J, false>(p, t);  // every level's row is y-interior
     else fin = levels<J, true>(p, t);
@@ -332,6 +422,14 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK) void k_jacobi_tb(
 }
 
 template <int K, int C>
+__global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK) void k_jacobi_div_tb(
+    Geom g, int r0, int r1, int chunk, const float2 *__restrict__ vel, float *__restrict__ div_out,
+    float *__restrict__ pout, float *__restrict__ dump) {
+  typename JacobiDivOp<C>::P p{vel, div_out, pout, dump, g.n};
+  tb_kernel_body<JacobiDivOp<C>, K, C>(g, r0, r1, chunk, p);
+}
+
+template <int K, int C>
 __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK) void k_diffuse_tb(
     Geom g, int r0, int r1, int chunk, float alpha, float beta, const float2 *__restrict__ vin,
     float2 *__restrict__ vout, float2 *__restrict__ dump) {
@@ -352,6 +450,13 @@ void jacobi_tb_launch(hipStream_t s, Geom g, int r0, int r1, int chunk, const fl
   const dim3 grid = tb_grid<K, C>(g, r0, r1, chunk);
   k_jacobi_tb<K, C><<<grid, dim3(WAVE * WAVES_PER_BLOCK), 0, s>>>(g, r0, r1, chunk, pin, div, pout,
                                                                  (float *)dump);
+}
+template <int K, int C>
+void jacobi_div_tb_launch(hipStream_t s, Geom g, int r0, int r1, int chunk, const float2 *vel,
+                          float *div_out, float *pout, void *dump) {
+  const dim3 grid = tb_grid<K, C>(g, r0, r1, chunk);
+  k_jacobi_div_tb<K, C><<<grid, dim3(WAVE * WAVES_PER_BLOCK), 0, s>>>(g, r0, r1, chunk, vel, div_out,
+                                                                     pout, (float *)dump);
 }
 template <int K, int C>
 void diffuse_tb_launch(hipStream_t s, Geom g, int r0, int r1, int chunk, float alpha, float beta,
@@ -400,6 +505,16 @@ bool launch_jacobi_tb(hipStream_t s, Geom g, int r0, int r1, int k, int cols, in
   if (cols == 4) { TB_DISPATCH_K(jacobi_tb_launch, 4, s, g, r0, r1, chunk, pin, div, pout, dump) return false; }
   TB_DISPATCH_K(jacobi_tb_launch, 2, s, g, r0, r1, chunk, pin, div, pout, dump)
   TB_DISPATCH_K_DEEP(jacobi_tb_launch, 2, s, g, r0, r1, chunk, pin, div, pout, dump)
+  return false;
+}
+
+bool launch_jacobi_div_tb(hipStream_t s, Geom g, int r0, int r1, int k, int cols, int chunk,
+                          const float2 *vel, float *div_out, float *pout, void *dump) {
+  if (r1 <= r0) return true;
+  if (!tb_supported(g.n, cols) || chunk < 1 || !tb_has_k(k, cols, false)) return false;
+  if (cols == 4) { TB_DISPATCH_K(jacobi_div_tb_launch, 4, s, g, r0, r1, chunk, vel, div_out, pout, dump) return false; }
+  TB_DISPATCH_K(jacobi_div_tb_launch, 2, s, g, r0, r1, chunk, vel, div_out, pout, dump)
+  TB_DISPATCH_K_DEEP(jacobi_div_tb_launch, 2, s, g, r0, r1, chunk, vel, div_out, pout, dump)
   return false;
 }
 
