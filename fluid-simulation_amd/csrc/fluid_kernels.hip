@@ -78,26 +78,60 @@ __device__ __forceinline__ float2 linear_at_int(const float2 *t, Geom g, int m, 
   const size_t id = (size_t)r * g.n + x;                  \
   const bool interior = x > 0 && x < g.n - 1 && y > 0 && y < g.n - 1;
 
+// Rows per thread in the two advection kernels.  A backtrace is two dependent memory round
+// trips (own velocity, then the four texels), so a one-cell-per-thread kernel is bound by the
+// number of waves in flight, not by bandwidth (measured 3.2 TB/s); each thread therefore
+// issues the loads of ADV_ROWS cells before it consumes any of them.
+constexpr int ADV_ROWS_VEL = 4;   // measured: 1.33 -> 1.23 ms at 16384^2
+constexpr int ADV_ROWS_DENS = 1;  // float4 texels: more rows cost occupancy (1.82 -> 2.08 ms with 4)
+
+#define ADVECT_PROLOGUE                                        \
+  const int x = blockIdx.x * BX + threadIdx.x;                 \
+  const int rbase = r0 + (blockIdx.y * BY + threadIdx.y) * ADV_ROWS; \
+  if (x >= g.n) return;
+
 // kernel.cu:114-140
 __global__ __launch_bounds__(BX *BY) void k_advect_vel(Geom g, int r0, int r1, Valid valid, float dt,
                                                         const float2 *__restrict__ vin,
                                                         float2 *__restrict__ vout, int *flag) {
-  CELL_PROLOGUE
-  if (interior) {
-    float2 v = vin[id];
-    float px = (float)x - dt * v.x;
-    float py = (float)y - dt * v.y;
+  constexpr int ADV_ROWS = ADV_ROWS_VEL;
+  ADVECT_PROLOGUE
+  float2 v[ADV_ROWS];
+#pragma unroll
+  for (int k = 0; k < ADV_ROWS; ++k) {
+    const int r = min(rbase + k, r1 - 1);  // clamped duplicate rows are computed but not stored
+    v[k] = vin[(size_t)r * g.n + x];
+  }
+  // Branch-free main path for every cell (the gather is in bounds for any cell thanks to the
+  // clamps), so the 4 x ADV_ROWS texel loads are all in flight together; border cells are
+  // overwritten afterwards on a rarely taken path.
+  float2 o[ADV_ROWS];
+#pragma unroll
+  for (int k = 0; k < ADV_ROWS; ++k) {
+    const int y = g.ybase + min(rbase + k, r1 - 1);
+    float px = (float)x - dt * v[k].x;
+    float py = (float)y - dt * v[k].y;
     px = fmaxf(0.0f, fminf(px, (float)g.n));
     py = fmaxf(0.0f, fminf(py, (float)g.n));
-    vout[id] = bilinear(vin, g, px, py, valid, flag);
-  } else {
-    float2 o = make_float2(0.0f, 0.0f);
-    if (x == 0) o = neg(linear_at_int(vin, g, x + 1, y));
-    if (x == g.n - 1) o = neg(linear_at_int(vin, g, x - 1, y));
-    if (y == 0) o = neg(linear_at_int(vin, g, x + 1, y + 1));
-    if (y == g.n - 1) o = neg(linear_at_int(vin, g, x + 1, y - 1));
-    vout[id] = o;
+    const bool interior = x > 0 && x < g.n - 1 && y > 0 && y < g.n - 1;
+    o[k] = bilinear(vin, g, px, py, valid, interior ? flag : nullptr);  // border cells: discarded
   }
+#pragma unroll
+  for (int k = 0; k < ADV_ROWS; ++k) {
+    const int y = g.ybase + min(rbase + k, r1 - 1);
+    const bool interior = x > 0 && x < g.n - 1 && y > 0 && y < g.n - 1;
+    if (!interior) {
+      float2 b = make_float2(0.0f, 0.0f);
+      if (x == 0) b = neg(linear_at_int(vin, g, x + 1, y));
+      if (x == g.n - 1) b = neg(linear_at_int(vin, g, x - 1, y));
+      if (y == 0) b = neg(linear_at_int(vin, g, x + 1, y + 1));
+      if (y == g.n - 1) b = neg(linear_at_int(vin, g, x + 1, y - 1));
+      o[k] = b;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < ADV_ROWS; ++k)
+    if (rbase + k < r1) vout[(size_t)(rbase + k) * g.n + x] = o[k];
 }
 
 // kernel.cu:142-165
@@ -105,17 +139,29 @@ __global__ __launch_bounds__(BX *BY) void k_advect_dens(Geom g, int r0, int r1, 
                                                          const float2 *__restrict__ vel,
                                                          const float4 *__restrict__ din,
                                                          float4 *__restrict__ dout, int *flag) {
-  CELL_PROLOGUE
-  if (interior) {
-    float2 v = vel[id];
-    float px = (float)x - dt * v.x;
-    float py = (float)y - dt * v.y;
+  constexpr int ADV_ROWS = ADV_ROWS_DENS;
+  ADVECT_PROLOGUE
+  float2 v[ADV_ROWS];
+#pragma unroll
+  for (int k = 0; k < ADV_ROWS; ++k) {
+    const int r = min(rbase + k, r1 - 1);
+    v[k] = vel[(size_t)r * g.n + x];
+  }
+  float4 o[ADV_ROWS];
+#pragma unroll
+  for (int k = 0; k < ADV_ROWS; ++k) {
+    const int y = g.ybase + min(rbase + k, r1 - 1);
+    float px = (float)x - dt * v[k].x;
+    float py = (float)y - dt * v[k].y;
     px = fmaxf(0.0f, fminf(px, (float)g.n));
     py = fmaxf(0.0f, fminf(py, (float)g.n));
-    dout[id] = bilinear(din, g, px, py, valid, flag);
-  } else {
-    dout[id] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const bool interior = x > 0 && x < g.n - 1 && y > 0 && y < g.n - 1;
+    o[k] = bilinear(din, g, px, py, valid, interior ? flag : nullptr);
+    if (!interior) o[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   }
+#pragma unroll
+  for (int k = 0; k < ADV_ROWS; ++k)
+    if (rbase + k < r1) dout[(size_t)(rbase + k) * g.n + x] = o[k];
 }
 
 // kernel.cu:173-205 (one sweep)
@@ -239,6 +285,10 @@ __global__ __launch_bounds__(BX *BY) void k_add_vorticity(Geom g, int r0, int r1
 inline dim3 grid_for(Geom g, int r0, int r1) {
   return dim3((g.n + BX - 1) / BX, (r1 - r0 + BY - 1) / BY);
 }
+inline dim3 grid_adv(Geom g, int r0, int r1, int rows_per_thread) {
+  const int per_block = BY * rows_per_thread;
+  return dim3((g.n + BX - 1) / BX, (r1 - r0 + per_block - 1) / per_block);
+}
 const dim3 kBlock(BX, BY);
 
 }  // namespace
@@ -246,7 +296,7 @@ const dim3 kBlock(BX, BY);
 void launch_advect_vel(hipStream_t s, Geom g, int r0, int r1, int vlo, int vhi, float dt,
                        const float2 *vin, float2 *vout, int *flag) {
   if (r1 <= r0) return;
-  hipLaunchKernelGGL(k_advect_vel, grid_for(g, r0, r1), kBlock, 0, s, g, r0, r1, Valid{vlo, vhi}, dt,
+  hipLaunchKernelGGL(k_advect_vel, grid_adv(g, r0, r1, ADV_ROWS_VEL), kBlock, 0, s, g, r0, r1, Valid{vlo, vhi}, dt,
                      vin, vout, flag);
 }
 void launch_diffuse(hipStream_t s, Geom g, int r0, int r1, float alpha, float beta,
@@ -271,7 +321,7 @@ void launch_project(hipStream_t s, Geom g, int r0, int r1, const float2 *vin, co
 void launch_advect_dens(hipStream_t s, Geom g, int r0, int r1, int vlo, int vhi, float dt,
                         const float2 *vel, const float4 *din, float4 *dout, int *flag) {
   if (r1 <= r0) return;
-  hipLaunchKernelGGL(k_advect_dens, grid_for(g, r0, r1), kBlock, 0, s, g, r0, r1, Valid{vlo, vhi}, dt,
+  hipLaunchKernelGGL(k_advect_dens, grid_adv(g, r0, r1, ADV_ROWS_DENS), kBlock, 0, s, g, r0, r1, Valid{vlo, vhi}, dt,
                      vel, din, dout, flag);
 }
 void launch_add_force(hipStream_t s, Geom g, int r0, int r1, float dt, float radius, float sx,
