@@ -51,7 +51,7 @@ struct fluid_ctx {
   hipStream_t own_stream = nullptr, stream = nullptr;
   std::map<int, GraphEntry> graphs;
   // temporal-blocking plan (fused path): sweeps per launch, columns per lane, target waves
-  int tb_kj = 10, tb_kd = 5, tb_cj = 2, tb_cd = 2, tb_waves = 8192;
+  int tb_kj = 10, tb_kd = 5, tb_cj = 2, tb_cd = 2, tb_waves = 8192, tb_minchunk = 4;
   bool prof = false;
   std::vector<hipEvent_t> ev_pool;
   size_t ev_used = 0;
@@ -176,7 +176,7 @@ int tb_chunk(const fluid_ctx *c, int k, int cols, int rows) {
   const int strips = (c->g.n + vw - 1) / vw;
   const int chunks = c->tb_waves / strips > 1 ? c->tb_waves / strips : 1;
   int chunk = (rows + chunks - 1) / chunks;
-  if (chunk < 4 * k) chunk = 4 * k;  // keep the y-halo recompute below ~1/3
+  if (chunk < c->tb_minchunk * k) chunk = c->tb_minchunk * k;  // bound the y-halo recompute (2k rows per chunk)
   return chunk;
 }
 
@@ -433,14 +433,20 @@ int fluid_init(fluid_ctx **out, const fluid_params *p) {
   c->has_hi = si.has_hi;
   // tuning knobs (defaults chosen from measurements); results do not depend on them
   c->tb_kj = env_int("FLUID_TB_KJ", c->tb_kj);
-  // measured: two 5-sweep diffusion launches win while the fields sit in the
-  // Infinity Cache; from 8192^2 cells up one 10-sweep
-  // launch wins (HBM round trips dominate); likewise 10 vs 14 Jacobi sweeps per launch
-  if ((long long)prm.n * si.rows >= (1ll << 26)) { c->tb_kd = 10; c->tb_kj = 14; }
+  // Plan by owned cells, from sweeps on MI355X (tools/tb_sweep.py, tools/small_sweep.py):
+  //   <= ~1024^2 : launch/latency bound -> short pipelines, as many waves as possible
+  //   ~2048^2    : 5 sweeps per launch
+  //   ~4096^2    : fields sit in the Infinity Cache -> 10 Jacobi / 5 diffusion sweeps per launch
+  //   >= 8192^2  : HBM round trips dominate -> 13-14 Jacobi / 10 diffusion sweeps per launch
+  const long long owned = (long long)prm.n * si.rows;
+  if (owned < (1ll << 21)) { c->tb_kj = 5; c->tb_minchunk = 1; }
+  else if (owned < (1ll << 23)) { c->tb_kj = 5; }
+  else if (owned >= (1ll << 26)) { c->tb_kd = 10; c->tb_kj = 14; }
   c->tb_kd = env_int("FLUID_TB_KD", c->tb_kd);
   c->tb_cj = env_int("FLUID_TB_CJ", c->tb_cj);
   c->tb_cd = env_int("FLUID_TB_CD", c->tb_cd);
   c->tb_waves = env_int("FLUID_TB_WAVES", c->tb_waves);
+  c->tb_minchunk = env_int("FLUID_TB_MINCHUNK", c->tb_minchunk);
   c->alpha = 1.0f / (prm.viscosity * prm.dt);  // kernel.cu:182, fp32 at run time
   c->beta = 1.0f / (4.0f + c->alpha);          // kernel.cu:183
   int rc = [&]() -> int {
