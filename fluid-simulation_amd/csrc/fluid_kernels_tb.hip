@@ -26,6 +26,14 @@ namespace {
 
 constexpr int WAVE = 64;
 constexpr int WAVES_PER_BLOCK = 4;
+// Prefetch ring depth = unroll factor of the time loop (a multiple of 3, the period of the
+// level slots).  Measured on MI355X (tools/ubench/valu_rate.hip): one wave issues a VALU op
+// only every ~8 cycles, and it takes 4-8 waves per SIMD to approach 2.5-3; these pipelines run
+// at 2-4 waves per SIMD, so a wave parked on a load costs issue rate directly.  Six rows of
+// prefetch were tried against three: no measurable change (0.967 ms either way for the 13-sweep
+// Jacobi launch at 16384^2) at +18 VGPRs and twice the code, so the ring stays at three: the
+// kernels are bound by VALU issue at their occupancy, not by load latency.
+constexpr int RING = 3;
 
 // value held by lane-1 / lane+1 (DPP wave shift; every lane must be active)
 __device__ __forceinline__ float from_left(float v) {
@@ -146,15 +154,14 @@ template <int C> struct JacobiOp {
 
   // Divergence rows come from memory through a three-slot ring indexed by the phase.
   template <bool XEDGE> struct Feed {
-    A apf[3];  // in phase J: apf[J] = row t, apf[J+1] = row t+1, apf[J+2] = row t-1 (then reloaded: t+2)
+    A apf[RING];  // in phase J: apf[J + i] = row t - 1 + i, i = 0 .. RING-1
     template <class PipeT> __device__ __forceinline__ void init(const PipeT &pp, const P &p, int t0) {
-      apf[0] = load_aux(p, pp.off(t0));
-      apf[1] = load_aux(p, pp.off(t0 + 1));
-      apf[2] = zero_aux();  // "row t0-1": never feeds a stored row
+#pragma unroll
+      for (int i = 0; i < RING; ++i) apf[i] = load_aux(p, pp.off(t0 - 1 + i));
     }
     template <int J, class PipeT> __device__ __forceinline__ A next(const PipeT &pp, const P &p, int t) {
-      A r = apf[(J + 2) % 3];                        // row t-1 (loaded three steps ago)
-      apf[(J + 2) % 3] = load_aux(p, pp.off(t + 2));  // prefetch row t+2 into the freed slot
+      A r = apf[J % RING];                                  // row t-1
+      apf[J % RING] = load_aux(p, pp.off(t - 1 + RING));    // refill the freed slot
       return r;
     }
   };
@@ -254,21 +261,20 @@ template <int C> struct JacobiDivOp : JacobiOp<C> {
   }
 
   template <bool XEDGE> struct Feed {
-    Row2<C> vpf[3];  // velocity ring: in phase J slot J holds row t+1 (issued three steps ago)
+    Row2<C> vpf[RING];  // velocity ring: in phase J slot J + i holds row t + 1 + i
     Row2<C> va, vb;  // velocity rows t-1 and t
     A dcur;          // divergence row t-1
     template <class PipeT> __device__ __forceinline__ void init(const PipeT &pp, const P &p, int t0) {
       va = zero_row2<C>();
       vb = load_row2<C>(p.vel + pp.off(t0));
-      vpf[0] = load_row2<C>(p.vel + pp.off(t0 + 1));
-      vpf[1] = load_row2<C>(p.vel + pp.off(t0 + 2));
-      vpf[2] = load_row2<C>(p.vel + pp.off(t0 + 3));
+#pragma unroll
+      for (int i = 0; i < RING; ++i) vpf[i] = load_row2<C>(p.vel + pp.off(t0 + 1 + i));
       dcur = zero_row<C>();
     }
     template <int J, class PipeT> __device__ __forceinline__ A next(const PipeT &pp, const P &p, int t) {
       const A ret = dcur;                               // divergence row t-1
-      const Row2<C> vc = vpf[J % 3];                    // velocity row t+1
-      vpf[J % 3] = load_row2<C>(p.vel + pp.off(t + 4));  // prefetch three steps ahead
+      const Row2<C> vc = vpf[J % RING];                          // velocity row t+1
+      vpf[J % RING] = load_row2<C>(p.vel + pp.off(t + 1 + RING));  // refill the freed slot
       A d;
       const int N = pp.g.n;
       if (t <= 0 || t >= N - 1) {  // wave-uniform: border rows, kernel.cu:287
@@ -314,7 +320,7 @@ template <class Op, int K, bool XEDGE> struct Pipe {
   using P = typename Op::P;
   R s[K + 1][3];
   A dv[K];   // dv[l] = aux row needed by level l+1 this step (row t-l-1)
-  R pf[3];   // prefetch ring: in phase J, pf[J] = level-0 row t, pf[J+1] = row t+1, pf[J+2] = row t+2 (loading)
+  R pf[RING];  // prefetch ring: in phase J, pf[J + i] = level-0 row t + i
   typename Op::template Feed<XEDGE> feed;  // where the auxiliary rows come from
   Geom g;
   int x0, xc, ya, yb;  // xc: x0 clamped into the domain (address of this lane's loads)
@@ -340,9 +346,8 @@ template <class Op, int K, bool XEDGE> struct Pipe {
       for (int j = 0; j < 3; ++j) s[l][j] = Op::zero();
       dv[l] = Op::zero_aux();
     }
-    pf[0] = ld(p, t0);
-    pf[1] = ld(p, t0 + 1);
-    pf[2] = Op::zero();
+#pragma unroll
+    for (int i = 0; i < RING; ++i) pf[i] = ld(p, t0 + i);
     feed.init(*this, p, t0);
   }
 
@@ -359,15 +364,15 @@ template <class Op, int K, bool XEDGE> struct Pipe {
   }
 
   // One time step.  Nothing loop-carried changes register: the rings are indexed by the phase,
-  // so the loads issued here are first touched two steps later (counted vmcnt, not vmcnt(0)).
+  // so the loads issued here are first touched RING steps later (counted vmcnt, not vmcnt(0)).
   template <int J>
   __device__ __forceinline__ void step(const P &p, int t) {
 #pragma unroll
     for (int l = K - 1; l > 0; --l) dv[l] = dv[l - 1];
     dv[0] = feed.template next<J>(*this, p, t);  // aux row t-1
     if constexpr (Op::kLoadsField) {
-      s[0][(J + 2) % 3] = pf[J % 3];   // level 0, row t
-      pf[(J + 2) % 3] = ld(p, t + 2);  // prefetch two rows ahead into the slot just freed
+      s[0][(J + 2) % 3] = pf[J % RING];  // level 0, row t
+      pf[J % RING] = ld(p, t + RING);    // refill the freed slot: RING rows of prefetch
     }
     R fin;
     if (t - K >= 1 && t - 1 <= g.n - 2) fin = levels<J, false>(p, t);  // every level's row is y-interior
@@ -379,10 +384,16 @@ template <class Op, int K, bool XEDGE> struct Pipe {
   __device__ __forceinline__ void run(const P &p) {
     const int t0 = ya - K, t1 = yb + K;
     init(p, t0);
-    for (int t = t0; t < t1; t += 3) {  // up to two surplus steps: loads and stores are guarded
+    static_assert(RING == 3 || RING == 6, "the unrolled body below handles RING 3 and 6");
+    for (int t = t0; t < t1; t += RING) {  // up to RING-1 surplus steps: loads are clamped, stores dumped
       step<0>(p, t);
       step<1>(p, t + 1);
       step<2>(p, t + 2);
+      if constexpr (RING == 6) {
+        step<3>(p, t + 3);
+        step<4>(p, t + 4);
+        step<5>(p, t + 5);
+      }
     }
   }
 };
@@ -414,6 +425,8 @@ __device__ __forceinline__ void tb_kernel_body(Geom g, int r0, int r1, int chunk
 }
 
 template <int K, int C>
+// (Holding the 13-sweep form to 128 VGPRs for a fourth wave per SIMD was tried: 7 spilled
+// registers, 0.967 -> 1.133 ms per launch at 16384^2.  Left to the register allocator.)
 __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK) void k_jacobi_tb(
     Geom g, int r0, int r1, int chunk, const float *__restrict__ pin,
     const float *__restrict__ div, float *__restrict__ pout, float *__restrict__ dump) {
