@@ -17,11 +17,37 @@ def run_multi(pkg, args, n, D, J, flags):
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
                          f"--nproc-per-node {args.gpus}")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    # FLUID_BENCH_BACKEND=gloo + FLUID_BENCH_ONE_GPU=1: rehearsal of this code path with several
+    # ranks on a single GPU (RCCL refuses two ranks per device); never the measured configuration.
+    backend = os.environ.get("FLUID_BENCH_BACKEND", "nccl")
+    if os.environ.get("FLUID_BENCH_ONE_GPU"):
+        local = 0
     torch.cuda.set_device(local)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
 
+    # Self-check on the real transport before timing: the overlapped exchange must give the bits
+    # of the plain one (3 steps from the same splats); otherwise time the plain path.
+    import numpy as np
+    overlap_ok = True
+    if os.environ.get("FLUID_SLAB_OVERLAP", "1") != "0":
+        sums = []
+        for ov in (True, False):
+            s_ = SlabSim(pkg, n, rank=rank, world=world, device_index=local, diffusion_iters=D,
+                         pressure_iters=J, flags=flags, overlap=ov)
+            seeded_warm_state(pkg, s_)
+            s_.step(3)
+            s_.sync()
+            sums.append([int(s_.read(f).view(np.uint32).sum(dtype=np.uint64))
+                         for f in (pkg.FIELD_VELOCITY, pkg.FIELD_DENSITY, pkg.FIELD_PRESSURE)])
+            s_.close()
+        ok = torch.tensor([int(sums[0] == sums[1])], device="cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        overlap_ok = bool(ok.item())
     sim = SlabSim(pkg, n, rank=rank, world=world, device_index=local, diffusion_iters=D,
-                  pressure_iters=J, flags=flags)
+                  pressure_iters=J, flags=flags, overlap=None if overlap_ok else False)
     seeded_warm_state(pkg, sim)          # every rank applies the same splats to its own rows
     sim.step(args.warmup)
     sim.sync()
@@ -55,7 +81,9 @@ def run_multi(pkg, args, n, D, J, flags):
             "step_alg_bytes_per_cell": bpc,
             "step_effective_GBps": round(bpc * n * n / t_step / 1e9, 1),
             "step_frac_of_hbm_peak": round(bpc * n * n / t_step / 1e9 / (HBM_PEAK_GBPS * world), 4),
-            "halo_bytes_per_step_per_rank": sim.ex.bytes_per_step,
+            "transport": "RCCL (torch.distributed nccl)" if backend == "nccl" else backend,
+            "halo_bytes_per_step_per_rank": sim.ex.bytes_moved // max(args.steps + args.warmup, 1),
+            "overlap": sim.overlap, "overlap_matches_plain_exchange": overlap_ok,
         }
         print(json.dumps(out), flush=True)
     sim.close()

@@ -26,7 +26,9 @@ ABI_SYMBOLS = [
     "fluid_strerror", "fluid_last_error", "fluid_time_steps", "fluid_profile_steps",
     "fluid_stream", "fluid_set_stream",
     "fluid_slab_plan", "fluid_halo_bytes", "fluid_halo_pack", "fluid_halo_unpack",
+    "fluid_step_part", "fluid_halo_bytes_part", "fluid_halo_pack_part", "fluid_halo_unpack_part",
 ]
+PART_VELOCITY, PART_DENSITY = 1, 2
 
 
 class FluidParams(C.Structure):
@@ -118,6 +120,10 @@ class FluidLib:
         sig("fluid_halo_bytes", C.c_size_t, P, C.c_int, required=False)
         sig("fluid_halo_pack", C.c_int, P, C.c_int, P, required=False)
         sig("fluid_halo_unpack", C.c_int, P, C.c_int, P, required=False)
+        sig("fluid_step_part", C.c_int, P, C.c_int, required=False)
+        sig("fluid_halo_bytes_part", C.c_size_t, P, C.c_int, C.c_int, required=False)
+        sig("fluid_halo_pack_part", C.c_int, P, C.c_int, C.c_int, P, P, required=False)
+        sig("fluid_halo_unpack_part", C.c_int, P, C.c_int, C.c_int, P, P, required=False)
 
     def slab_plan(self, n, slab_rank, slab_count, *, diffusion_iters=None, pressure_iters=None,
                   halo_rows=0) -> dict:
@@ -291,6 +297,20 @@ class FluidSim:
     def halo_unpack(self, direction: int, dev_ptr: int):
         self._chk(self.lib.dll.fluid_halo_unpack(self._h, direction, C.c_void_p(dev_ptr)),
                   "fluid_halo_unpack")
+
+    def step_part(self, part: int):
+        self._chk(self.lib.dll.fluid_step_part(self._h, part), "fluid_step_part")
+
+    def halo_bytes_part(self, direction: int, parts: int) -> int:
+        return self.lib.dll.fluid_halo_bytes_part(self._h, direction, parts)
+
+    def halo_pack_part(self, direction: int, part: int, dev_ptr: int, stream: int = 0):
+        self._chk(self.lib.dll.fluid_halo_pack_part(self._h, direction, part, C.c_void_p(dev_ptr),
+                                                    C.c_void_p(stream)), "fluid_halo_pack_part")
+
+    def halo_unpack_part(self, direction: int, part: int, dev_ptr: int, stream: int = 0):
+        self._chk(self.lib.dll.fluid_halo_unpack_part(self._h, direction, part, C.c_void_p(dev_ptr),
+                                                      C.c_void_p(stream)), "fluid_halo_unpack_part")
 
     def stream(self) -> int:
         return self.lib.dll.fluid_stream(self._h) or 0

@@ -290,14 +290,16 @@ void enq_advect_density(fluid_ctx *c) {
 }
 
 // simulationStep()  kernel.cu:701-708
-void enq_step(fluid_ctx *c) {
-  // margins of the dependency cone (zero-width for whole-domain contexts, see widened())
-  const int m_diff = c->prm.pressure_iters + 1;  // diffused velocity feeds divergence on J rows
-  enq_advect_velocity(c, m_diff + c->prm.diffusion_iters);
-  enq_diffuse(c, m_diff);
-  if (c->prm.flags & FLUID_FLAG_VORTICITY) enq_vorticity(c);  // kernel.cu:705
-  enq_project(c);
-  enq_advect_density(c);
+void enq_step(fluid_ctx *c, int parts) {
+  if (parts & FLUID_PART_VELOCITY) {
+    // margins of the dependency cone (zero-width for whole-domain contexts, see widened())
+    const int m_diff = c->prm.pressure_iters + 1;  // diffused velocity feeds divergence on J rows
+    enq_advect_velocity(c, m_diff + c->prm.diffusion_iters);
+    enq_diffuse(c, m_diff);
+    if (c->prm.flags & FLUID_FLAG_VORTICITY) enq_vorticity(c);  // kernel.cu:705
+    enq_project(c);
+  }
+  if (parts & FLUID_PART_DENSITY) enq_advect_density(c);
 }
 
 int check_launch(fluid_ctx *c) {
@@ -306,24 +308,24 @@ int check_launch(fluid_ctx *c) {
   return FLUID_OK;
 }
 
-int run_steps(fluid_ctx *c, int nsteps) {
+int run_steps(fluid_ctx *c, int nsteps, int parts = FLUID_PART_VELOCITY | FLUID_PART_DENSITY) {
   const bool direct = (c->prm.flags & FLUID_FLAG_NO_GRAPH) || c->prof;
   for (int s = 0; s < nsteps; ++s) {
     if (direct) {
-      enq_step(c);
+      enq_step(c, parts);
       int rc = check_launch(c);
       if (rc) return rc;
       continue;
     }
-    const int key = state_of(c);
+    const int key = state_of(c) | (parts << 3);
     auto it = c->graphs.find(key);
     if (it == c->graphs.end()) {
       GraphEntry ge;
       HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-      enq_step(c);
+      enq_step(c, parts);
       hipError_t e = hipStreamEndCapture(c->stream, &ge.graph);
       ge.next_state = state_of(c);
-      set_state(c, key);
+      set_state(c, key & 7);
       if (e != hipSuccess) return fail(c, FLUID_E_DEVICE, "hipStreamEndCapture: %s", hipGetErrorString(e));
       HIPCHK(c, hipGraphInstantiate(&ge.exec, ge.graph, nullptr, nullptr, 0));
       it = c->graphs.emplace(key, ge).first;
@@ -669,10 +671,60 @@ int fluid_profile_steps(fluid_ctx *c, int nsteps, fluid_kernel_stat *stats, int 
   return FLUID_OK;
 }
 
-size_t fluid_halo_bytes(const fluid_ctx *c, int dir) {
+int fluid_step_part(fluid_ctx *c, int part) {
+  if (!c || (part != FLUID_PART_VELOCITY && part != FLUID_PART_DENSITY)) return FLUID_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->prm.device));
+  return run_steps(c, 1, part);
+}
+
+size_t fluid_halo_bytes_part(const fluid_ctx *c, int dir, int parts) {
   if (!c || !c->slab) return 0;
   if ((dir < 0 && !c->has_lo) || (dir > 0 && !c->has_hi) || dir == 0) return 0;
-  return (size_t)c->g.n * ((size_t)c->halo_vel * sizeof(float2) + (size_t)c->halo_dens * sizeof(float4));
+  size_t b = 0;
+  if (parts & FLUID_PART_VELOCITY) b += (size_t)c->g.n * c->halo_vel * sizeof(float2);
+  if (parts & FLUID_PART_DENSITY) b += (size_t)c->g.n * c->halo_dens * sizeof(float4);
+  return b;
+}
+
+size_t fluid_halo_bytes(const fluid_ctx *c, int dir) {
+  return fluid_halo_bytes_part(c, dir, FLUID_PART_VELOCITY | FLUID_PART_DENSITY);
+}
+
+// One field's halo block; stream NULL = the context's stream.
+int fluid_halo_pack_part(fluid_ctx *c, int dir, int part, void *dst, void *stream) {
+  if (!c || !dst || (part != FLUID_PART_VELOCITY && part != FLUID_PART_DENSITY)) return FLUID_E_INVALID;
+  if (!fluid_halo_bytes_part(c, dir, part)) return FLUID_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->prm.device));
+  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  const size_t n = c->g.n;
+  if (part == FLUID_PART_VELOCITY) {
+    const size_t r = dir < 0 ? c->own_r0 : c->own_r0 + c->rows - c->halo_vel;
+    HIPCHK(c, hipMemcpyAsync(dst, c->vel[c->vin] + r * n, (size_t)c->halo_vel * n * sizeof(float2),
+                             hipMemcpyDeviceToDevice, st));
+  } else {
+    const size_t r = dir < 0 ? c->own_r0 : c->own_r0 + c->rows - c->halo_dens;
+    HIPCHK(c, hipMemcpyAsync(dst, c->dens[c->din] + r * n, (size_t)c->halo_dens * n * sizeof(float4),
+                             hipMemcpyDeviceToDevice, st));
+  }
+  return FLUID_OK;
+}
+
+int fluid_halo_unpack_part(fluid_ctx *c, int dir, int part, const void *src, void *stream) {
+  if (!c || !src || (part != FLUID_PART_VELOCITY && part != FLUID_PART_DENSITY)) return FLUID_E_INVALID;
+  if (!fluid_halo_bytes_part(c, dir, part)) return FLUID_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->prm.device));
+  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  const size_t n = c->g.n;
+  if (part == FLUID_PART_VELOCITY) {
+    const size_t r = dir < 0 ? c->own_r0 - c->halo_vel : c->own_r0 + c->rows;
+    HIPCHK(c, hipMemcpyAsync(c->vel[c->vin] + r * n, src, (size_t)c->halo_vel * n * sizeof(float2),
+                             hipMemcpyDeviceToDevice, st));
+  } else {
+    const size_t r = dir < 0 ? c->own_r0 - c->halo_dens : c->own_r0 + c->rows;
+    HIPCHK(c, hipMemcpyAsync(c->dens[c->din] + r * n, src, (size_t)c->halo_dens * n * sizeof(float4),
+                             hipMemcpyDeviceToDevice, st));
+  }
+  return FLUID_OK;
 }
 
 // Message layout: [halo_vel rows of float2][halo_dens rows of float4], rows in ascending y.

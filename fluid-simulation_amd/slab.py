@@ -18,54 +18,77 @@ from typing import Callable, Optional
 
 
 class HaloExchanger:
-    """Moves one step's halo messages between neighbouring ranks.
+    """Moves halo messages between neighbouring ranks (rank-1 below, rank+1 above).
 
-    ``pack(direction, ptr)`` must fill the send buffer at device/host address ``ptr`` with the
-    message for the neighbour in ``direction`` (-1: rank-1, +1: rank+1); ``unpack(direction,
-    ptr)`` consumes the message received from that neighbour.  Buffers are uint8 torch tensors on
-    ``device``; on CUDA the calling code must run on torch's current stream so that the NCCL
-    transfers are ordered after pack and before unpack.
+    One exchange = ``start`` (pack the send buffers, post all isend/irecv at once) and, later,
+    ``finish`` (wait, unpack).  Several exchanges, told apart by ``tag``, may be in flight at
+    the same time, each with its own buffers, so a transfer can hide behind compute.
+
+    ``pack(direction, ptr)`` fills the send buffer at device/host address ``ptr`` with the
+    message for the neighbour in ``direction`` (-1 / +1); ``unpack(direction, ptr)`` consumes the
+    message received from it.  Buffers are uint8 torch tensors on ``device``.  On CUDA with the
+    nccl (= RCCL) backend the transfers are stream-ordered: posted under the stream that ran
+    ``pack``, and ``finish`` makes the *current* stream wait for them (no host block).  Any other
+    backend reads the buffers from the host side, so the packing stream is synchronised first.
     """
 
-    def __init__(self, rank: int, world: int, bytes_lo: int, bytes_hi: int, device, group=None):
+    def __init__(self, rank: int, world: int, device, group=None):
         import torch
+        import torch.distributed as dist
         self.rank, self.world, self.group = rank, world, group
-        self.has_lo, self.has_hi = rank > 0 and bytes_lo > 0, rank < world - 1 and bytes_hi > 0
-        mk = lambda nbytes: torch.empty(nbytes, dtype=torch.uint8, device=device)
-        self.send_lo = mk(bytes_lo) if self.has_lo else None
-        self.recv_lo = mk(bytes_lo) if self.has_lo else None
-        self.send_hi = mk(bytes_hi) if self.has_hi else None
-        self.recv_hi = mk(bytes_hi) if self.has_hi else None
-        self.bytes_per_step = (bytes_lo if self.has_lo else 0) + (bytes_hi if self.has_hi else 0)
-        # NCCL/RCCL transfers are stream-ordered after the packs; any other backend reads the
-        # buffers from the host side, so the packs must have landed first.
-        import torch.distributed as dist
-        self.host_ordered = torch.device(device).type == "cuda" and dist.get_backend(group) != "nccl"
+        self.device = torch.device(device)
+        self.has_lo, self.has_hi = rank > 0, rank < world - 1
+        self.host_ordered = self.device.type == "cuda" and dist.get_backend(group) != "nccl"
+        self.buf = {}      # tag -> {(kind, dir): tensor}
+        self.pending = {}  # tag -> list of requests
+        self.bytes_moved = 0
 
-    def exchange(self, pack: Callable[[int, int], None], unpack: Callable[[int, int], None]):
+    def _buffers(self, tag, nbytes_lo, nbytes_hi):
+        import torch
+        b = self.buf.get(tag)
+        if b is None:
+            mk = lambda n: torch.empty(n, dtype=torch.uint8, device=self.device)
+            b = {}
+            if self.has_lo and nbytes_lo:
+                b[("send", -1)], b[("recv", -1)] = mk(nbytes_lo), mk(nbytes_lo)
+            if self.has_hi and nbytes_hi:
+                b[("send", +1)], b[("recv", +1)] = mk(nbytes_hi), mk(nbytes_hi)
+            self.buf[tag] = b
+        return b
+
+    def start(self, tag, nbytes_lo: int, nbytes_hi: int, pack: Callable[[int, int], None]):
+        import torch
         import torch.distributed as dist
-        if not (self.has_lo or self.has_hi):
-            return
-        ops = []
-        if self.has_lo:
-            pack(-1, self.send_lo.data_ptr())
-        if self.has_hi:
-            pack(+1, self.send_hi.data_ptr())
-        if self.host_ordered:
-            import torch
+        assert tag not in self.pending, f"exchange {tag!r} already in flight"
+        b = self._buffers(tag, nbytes_lo, nbytes_hi)
+        dirs = [d for d in (-1, +1) if ("send", d) in b]
+        for d in dirs:
+            pack(d, b[("send", d)].data_ptr())
+        if self.host_ordered and dirs:
             torch.cuda.current_stream().synchronize()
-        if self.has_lo:
-            ops.append(dist.P2POp(dist.isend, self.send_lo, self.rank - 1, self.group))
-            ops.append(dist.P2POp(dist.irecv, self.recv_lo, self.rank - 1, self.group))
-        if self.has_hi:
-            ops.append(dist.P2POp(dist.isend, self.send_hi, self.rank + 1, self.group))
-            ops.append(dist.P2POp(dist.irecv, self.recv_hi, self.rank + 1, self.group))
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()  # CUDA: the current stream waits for the transfer; no host block
-        if self.has_lo:
-            unpack(-1, self.recv_lo.data_ptr())
-        if self.has_hi:
-            unpack(+1, self.recv_hi.data_ptr())
+        ops = []
+        for d in dirs:
+            peer = self.rank + d
+            ops.append(dist.P2POp(dist.isend, b[("send", d)], peer, self.group))
+            ops.append(dist.P2POp(dist.irecv, b[("recv", d)], peer, self.group))
+            self.bytes_moved += b[("send", d)].numel()
+        self.pending[tag] = dist.batch_isend_irecv(ops) if ops else []
+
+    def finish(self, tag, unpack: Optional[Callable[[int, int], None]]):
+        """Wait for exchange ``tag``; ``unpack=None`` discards what was received."""
+        for req in self.pending.pop(tag):
+            req.wait()
+        if unpack is not None:
+            for (kind, d), t in self.buf[tag].items():
+                if kind == "recv":
+                    unpack(d, t.data_ptr())
+
+    def in_flight(self, tag) -> bool:
+        return tag in self.pending
+
+    def exchange(self, nbytes_lo, nbytes_hi, pack, unpack, tag="all"):
+        self.start(tag, nbytes_lo, nbytes_hi, pack)
+        self.finish(tag, unpack)
 
 
 class SlabSim:
@@ -73,30 +96,79 @@ class SlabSim:
 
     Mirrors :class:`FluidSim` (add_source / step / read); ``read`` returns the owned rows,
     ``gather`` assembles the whole field on rank 0.
+
+    ``overlap=True`` (default; env FLUID_SLAB_OVERLAP=0 turns it off) hides the halo traffic
+    behind compute: the step is run as its two parts (include/fluid.h fluid_step_part), and
+
+        velocity halos for step s+1 travel while step s's density advection runs,
+        density halos for step s+1 travel while step s+1's velocity part runs,
+
+    on a second stream.  Same messages, same results; only when they move differs.
     """
 
     def __init__(self, pkg, n: int, *, rank: int, world: int, device_index: int = 0, group=None,
-                 **params):
+                 overlap: Optional[bool] = None, **params):
+        import os
         import torch
         self.pkg, self.rank, self.world = pkg, rank, world
         self.torch = torch
         torch.cuda.set_device(device_index)
-        self.stream = torch.cuda.Stream(device=device_index)
+        self.stream = torch.cuda.Stream(device=device_index)       # kernels, unpack
+        self.comm_stream = torch.cuda.Stream(device=device_index)  # pack, transfers
         self.sim = pkg.FluidSim(n, device=device_index, slab_rank=rank, slab_count=world, **params)
-        # kernels, pack/unpack copies and the RCCL transfers are all ordered on this stream
         self.sim.set_stream(self.stream.cuda_stream)
         self.n, self.row0, self.rows = self.sim.n, self.sim.row0, self.sim.rows
-        self.ex = HaloExchanger(rank, world, self.sim.halo_bytes(-1), self.sim.halo_bytes(+1),
-                                torch.device("cuda", device_index), group)
+        self.overlap = (os.environ.get("FLUID_SLAB_OVERLAP", "1") != "0") if overlap is None else overlap
+        self.ex = HaloExchanger(rank, world, torch.device("cuda", device_index), group)
+        self.V, self.D = pkg.PART_VELOCITY, pkg.PART_DENSITY
 
+    # -- exchanges -------------------------------------------------------------------------
+    def _start(self, part):
+        """Post the halo exchange of one field; it is ordered after everything enqueued on the
+        compute stream so far and runs on the comm stream."""
+        sim, comm = self.sim, self.comm_stream
+        comm.wait_stream(self.stream)
+        with self.torch.cuda.stream(comm):
+            self.ex.start(part, sim.halo_bytes_part(-1, part), sim.halo_bytes_part(+1, part),
+                          lambda d, ptr: sim.halo_pack_part(d, part, ptr, comm.cuda_stream))
+
+    def _finish(self, part, keep=True):
+        sim = self.sim
+        with self.torch.cuda.stream(self.stream):
+            self.ex.finish(part, (lambda d, ptr: sim.halo_unpack_part(d, part, ptr, self.stream.cuda_stream))
+                           if keep else None)
+
+    def _discard_in_flight(self):
+        for part in (self.V, self.D):
+            if self.ex.in_flight(part):
+                self._finish(part, keep=False)
+
+    # -- the FluidSim interface ----------------------------------------------------------------
     def add_source(self, *a, **k):
+        self._discard_in_flight()  # halos already travelling would be stale after this
         self.sim.add_source(*a, **k)
 
     def step(self, nsteps: int = 1):
-        with self.torch.cuda.stream(self.stream):
-            for _ in range(nsteps):
-                self.ex.exchange(self.sim.halo_pack, self.sim.halo_unpack)
-                self.sim.step(1)
+        sim, V, D = self.sim, self.V, self.D
+        if not self.overlap:
+            with self.torch.cuda.stream(self.stream):
+                for _ in range(nsteps):
+                    self.ex.exchange(sim.halo_bytes(-1), sim.halo_bytes(+1), sim.halo_pack, sim.halo_unpack)
+                    sim.step(1)
+            return
+        for _ in range(nsteps):
+            if not self.ex.in_flight(V):
+                self._start(V)
+            if not self.ex.in_flight(D):
+                self._start(D)
+            self._finish(V)
+            with self.torch.cuda.stream(self.stream):
+                sim.step_part(V)
+            self._start(V)        # next step's velocity halos: travel during the density part
+            self._finish(D)
+            with self.torch.cuda.stream(self.stream):
+                sim.step_part(D)
+            self._start(D)        # next step's density halos: travel during the next velocity part
 
     def sync(self):
         self.sim.sync()
@@ -114,6 +186,8 @@ class SlabSim:
         return np.concatenate(parts, axis=0) if self.rank == 0 else None
 
     def close(self):
+        self._discard_in_flight()
+        self.sim.sync()
         self.sim.close()
 
 

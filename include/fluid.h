@@ -206,6 +206,23 @@ typedef struct fluid_slab_info {
 /* Pure host arithmetic (needs no GPU): the geometry fluid_init will use for p. */
 FLUID_API int fluid_slab_plan(const fluid_params *p, fluid_slab_info *out);
 FLUID_API size_t fluid_halo_bytes(const fluid_ctx *ctx, int dir);
+
+/* The same, one part at a time, so the exchange can hide behind compute:
+ *   FLUID_PART_VELOCITY = simulateAdvection + simulateDiffusion + projection  (kernel.cu:703-706)
+ *   FLUID_PART_DENSITY  = simulateDensityAdvection                            (kernel.cu:707)
+ * fluid_step(ctx, 1) == fluid_step_part(VELOCITY) then fluid_step_part(DENSITY).  The velocity
+ * part needs only velocity halos and the density part only density halos (and the projected
+ * velocity on the owned rows), so the velocity halos for step s+1 can travel while step s's
+ * density advection runs, and the density halos while step s+1's velocity part runs
+ * (fluid-simulation_amd/slab.py).  pack/unpack_part move one field's halo block; `stream` is the
+ * hipStream_t to enqueue the copy on (NULL = the context's stream).  Works on whole-domain
+ * contexts too (fluid_step_part only). */
+enum { FLUID_PART_VELOCITY = 1, FLUID_PART_DENSITY = 2 };
+FLUID_API int fluid_step_part(fluid_ctx *ctx, int part);
+FLUID_API size_t fluid_halo_bytes_part(const fluid_ctx *ctx, int dir, int parts);
+FLUID_API int fluid_halo_pack_part(fluid_ctx *ctx, int dir, int part, void *dev_dst, void *stream);
+FLUID_API int fluid_halo_unpack_part(fluid_ctx *ctx, int dir, int part, const void *dev_src,
+                                     void *stream);
 FLUID_API int fluid_halo_pack(fluid_ctx *ctx, int dir, void *dev_dst);
 FLUID_API int fluid_halo_unpack(fluid_ctx *ctx, int dir, const void *dev_src);
 

@@ -35,8 +35,7 @@ def main():
     row1 = row0 + rows
     assert plan["store_row0"] == row0 - (hv if rank > 0 else 0)
     nbytes = n * (hv * 8 + hd * 16)
-    ex = HaloExchanger(rank, world, nbytes if rank > 0 else 0, nbytes if rank < world - 1 else 0,
-                       torch.device("cpu"))
+    ex = HaloExchanger(rank, world, torch.device("cpu"))
 
     base = pkg.FluidSim(n, diffusion_iters=D, pressure_iters=J, lib=oracle)   # undecomposed run
     mine = pkg.FluidSim(n, diffusion_iters=D, pressure_iters=J, lib=oracle)   # my slab's view
@@ -72,7 +71,7 @@ def main():
                 vel[row1:row1 + hv] = v
                 dens[row1:row1 + hd] = q
 
-        ex.exchange(pack, unpack)
+        ex.exchange(nbytes, nbytes, pack, unpack)
         mine.write(pkg.FIELD_VELOCITY, vel)
         mine.write(pkg.FIELD_DENSITY, dens)
         mine.step(1)

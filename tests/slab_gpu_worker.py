@@ -16,15 +16,18 @@ import fluid_amd_loader  # noqa: E402
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     backend, n, J, steps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+    overlap = bool(int(sys.argv[5]))
     dist.init_process_group(backend, rank=rank, world_size=world)
     pkg = fluid_amd_loader.load()
     from fluid_simulation_amd.slab import SlabSim
-    sim = SlabSim(pkg, n, rank=rank, world=world, device_index=0, pressure_iters=J, halo_rows=2)
+    sim = SlabSim(pkg, n, rank=rank, world=world, device_index=0, pressure_iters=J, halo_rows=2,
+                  overlap=overlap)
     ss = pkg.SplatStream()
     for s in range(steps):
         if s % 2 == 0:
-            sim.add_source(*ss.splat())
+            sim.add_source(*ss.splat())   # also exercises discarding halos already in flight
         sim.step(1)
+    sim.step(3)                            # several steps in one call: exchanges chained back to back
     sim.sync()
     fields = {f: sim.gather(f) for f in (pkg.FIELD_VELOCITY, pkg.FIELD_DENSITY, pkg.FIELD_PRESSURE)}
     if rank == 0:
@@ -34,6 +37,7 @@ def main():
             if s % 2 == 0:
                 whole.add_source(*ss.splat())
             whole.step(1)
+        whole.step(3)
         for f, got in fields.items():
             want = whole.read(f)
             assert got.shape == want.shape

@@ -135,8 +135,9 @@ def test_slab_contexts_reject_what_they_cannot_do(pkg, hip):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("overlap", [0, 1], ids=["plain", "overlap"])
 @pytest.mark.parametrize("world", [2, 4])
-def test_slabsim_multiprocess_on_one_gpu(world):
+def test_slabsim_multiprocess_on_one_gpu(world, overlap):
     """The bench's multi-rank driver (SlabSim: stream hand-over, pack -> P2P -> unpack -> step) with
     one process per slab.  Only one GPU is available to tests and RCCL refuses two ranks on one
     device, so the ranks share device 0 and the transport is gloo; the RCCL leg differs only in
@@ -147,7 +148,7 @@ def test_slabsim_multiprocess_on_one_gpu(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), GLOO_SOCKET_IFNAME="lo")
         procs.append(subprocess.Popen(
-            [sys.executable, os.path.join(ROOT, "tests", "slab_gpu_worker.py"), "gloo", "512", "10", "6"],
+            [sys.executable, os.path.join(ROOT, "tests", "slab_gpu_worker.py"), "gloo", "512", "10", "6", str(overlap)],
             env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
     for p in procs:
@@ -160,3 +161,22 @@ def test_slabsim_multiprocess_on_one_gpu(world):
         outs.append(out)
     for r, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {r} failed:\n{out[-3000:]}"
+
+
+@pytest.mark.gpu
+def test_step_parts_equal_whole_step(pkg, hip):
+    """fluid_step(1) == fluid_step_part(VELOCITY) + fluid_step_part(DENSITY), whole-domain and slab
+    contexts alike (the slab variant also moves the two fields' halos separately)."""
+    import fluid_simulation_amd.slab as slab
+    n = 384
+    a, b = pkg.FluidSim(n, pressure_iters=12), pkg.FluidSim(n, pressure_iters=12)
+    for s in (a, b):
+        pkg.run_seeded(s, 3)
+    a.step(2)
+    for _ in range(2):
+        b.step_part(pkg.PART_VELOCITY)
+        b.step_part(pkg.PART_DENSITY)
+    for f in (pkg.FIELD_VELOCITY, pkg.FIELD_DENSITY, pkg.FIELD_PRESSURE, pkg.FIELD_DIVERGENCE):
+        assert_bit_equal(a.read(f), b.read(f), f"field {f}")
+    s = pkg.FluidSim(512, slab_rank=1, slab_count=4)
+    assert s.halo_bytes_part(-1, pkg.PART_VELOCITY) + s.halo_bytes_part(-1, pkg.PART_DENSITY) == s.halo_bytes(-1)
