@@ -77,7 +77,7 @@ def run_multi(pkg, args, n, D, J, flags):
                        "name": args.workload, "path": "unfused" if args.unfused else "fused",
                        "decomposition": f"{world} row slabs of {plan['rows']} rows, one halo exchange per "
                                         f"step ({plan['halo_vel']} velocity + {plan['halo_dens']} density rows "
-                                        f"per neighbour) over RCCL send/recv"},
+                                        f"per neighbour) over {'RCCL send/recv' if backend == 'nccl' else backend}"},
             "step_alg_bytes_per_cell": bpc,
             "step_effective_GBps": round(bpc * n * n / t_step / 1e9, 1),
             "step_frac_of_hbm_peak": round(bpc * n * n / t_step / 1e9 / (HBM_PEAK_GBPS * world), 4),
