@@ -96,11 +96,17 @@ def roofline_from_profile(sim, steps):
             traffic = pmc.get(dom["name"], {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
+    # `achieved` prices every sweep's algorithmic bytes (contract), so a temporally blocked
+    # launch of K sweeps can exceed the HBM peak; `traffic_frac` is the bytes the PMC counters
+    # saw actually crossing HBM over the same launch duration.
+    moved = traffic / (avg_ms * 1e-3) / 1e9 if traffic else None
     return {
         "bound": "hbm", "kernel": dom["name"], "achieved": round(achieved, 1),
         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
         "traffic": traffic, "avg_launch_ms": round(avg_ms, 5),
         "alg_bytes_per_launch": dom["alg_bytes"],
+        "traffic_GBps": round(moved, 1) if moved else None,
+        "traffic_frac": round(moved / HBM_PEAK_GBPS, 4) if moved else None,
     }, per_kernel
 
 
