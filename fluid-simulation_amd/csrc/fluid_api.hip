@@ -434,16 +434,17 @@ int fluid_init(fluid_ctx **out, const fluid_params *p) {
   c->has_lo = si.has_lo;
   c->has_hi = si.has_hi;
   // tuning knobs (defaults chosen from measurements); results do not depend on them
-  c->tb_kj = env_int("FLUID_TB_KJ", c->tb_kj);
   // Plan by owned cells, from sweeps on MI355X (tools/tb_sweep.py, tools/small_sweep.py):
   //   <= ~1024^2 : launch/latency bound -> short pipelines, as many waves as possible
   //   ~2048^2    : 5 sweeps per launch
   //   ~4096^2    : fields sit in the Infinity Cache -> 10 Jacobi / 5 diffusion sweeps per launch
-  //   >= 8192^2  : HBM round trips dominate -> 13-14 Jacobi / 10 diffusion sweeps per launch
+  //   >= 8192^2  : HBM round trips dominate -> 13-14 Jacobi / 10 diffusion sweeps per launch,
+  //                twice the waves (shorter chunks even out the tail of the launch)
   const long long owned = (long long)prm.n * si.rows;
   if (owned < (1ll << 21)) { c->tb_kj = 5; c->tb_minchunk = 1; }
   else if (owned < (1ll << 23)) { c->tb_kj = 5; }
-  else if (owned >= (1ll << 26)) { c->tb_kd = 10; c->tb_kj = 14; }
+  else if (owned >= (1ll << 26)) { c->tb_kd = 10; c->tb_kj = 14; c->tb_waves = 16384; c->tb_minchunk = 1; }
+  c->tb_kj = env_int("FLUID_TB_KJ", c->tb_kj);
   c->tb_kd = env_int("FLUID_TB_KD", c->tb_kd);
   c->tb_cj = env_int("FLUID_TB_CJ", c->tb_cj);
   c->tb_cd = env_int("FLUID_TB_CD", c->tb_cd);

@@ -52,15 +52,38 @@ __device__ __forceinline__ T texel(const T *t, Geom g, int i, int j, Valid v, in
   return t[(size_t)r * g.n + i];
 }
 
-// LINEAR fetch at texture coordinate (bx + .5, by + .5): SURVEY.md Appendix B.2.
+// LINEAR fetch at texture coordinate (bx + .5, by + .5): SURVEY.md Appendix B.2.  Split in two so
+// that a wave can decide between the gathers below once the texel indices are known.
+struct Tap { int i, j; float a, b; };
+__device__ __forceinline__ Tap tap_of(float bx, float by) {
+  const float fi = floorf(bx), fj = floorf(by);
+  return Tap{(int)fi, (int)fj, bx - fi, by - fj};
+}
 template <typename T>
-__device__ __forceinline__ T bilinear(const T *t, Geom g, float bx, float by, Valid v, int *flag) {
-  float fi = floorf(bx), fj = floorf(by);
-  float a = bx - fi, b = by - fj;
-  int i = (int)fi, j = (int)fj;
-  T v0 = mix(texel(t, g, i, j, v, flag), texel(t, g, i + 1, j, v, flag), a);
-  T v1 = mix(texel(t, g, i, j + 1, v, flag), texel(t, g, i + 1, j + 1, v, flag), a);
-  return mix(v0, v1, b);
+__device__ __forceinline__ T bilinear(const T *t, Geom g, Tap p, Valid v, int *flag) {
+  T v0 = mix(texel(t, g, p.i, p.j, v, flag), texel(t, g, p.i + 1, p.j, v, flag), p.a);
+  T v1 = mix(texel(t, g, p.i, p.j + 1, v, flag), texel(t, g, p.i + 1, p.j + 1, v, flag), p.a);
+  return mix(v0, v1, p.b);
+}
+// All four texels inside the domain and inside the rows that hold current data: no clamps, no
+// validity test, one address; the same four values, so the same result bit for bit.
+__device__ __forceinline__ bool tap_inside(Tap p, Geom g, Valid v) {
+  const int r = p.j - g.ybase;
+  return p.i >= 0 && p.i <= g.n - 2 && p.j >= 0 && p.j <= g.n - 2 && r >= v.lo && r + 1 < v.hi;
+}
+typedef float f4a8 __attribute__((ext_vector_type(4), aligned(8)));
+__device__ __forceinline__ float2 bilinear_inside(const float2 *t, Geom g, Tap p) {
+  const float2 *q = t + ((size_t)(p.j - g.ybase) * g.n + p.i);
+  const f4a8 lo = *reinterpret_cast<const f4a8 *>(q);         // texels (i, j), (i+1, j)
+  const f4a8 hi = *reinterpret_cast<const f4a8 *>(q + g.n);   // texels (i, j+1), (i+1, j+1)
+  const float2 v0 = mix(make_float2(lo.x, lo.y), make_float2(lo.z, lo.w), p.a);
+  const float2 v1 = mix(make_float2(hi.x, hi.y), make_float2(hi.z, hi.w), p.a);
+  return mix(v0, v1, p.b);
+}
+__device__ __forceinline__ float4 bilinear_inside(const float4 *t, Geom g, Tap p) {
+  const float4 *q = t + ((size_t)(p.j - g.ybase) * g.n + p.i);
+  const float4 t00 = q[0], t10 = q[1], t01 = q[g.n], t11 = q[g.n + 1];
+  return mix(mix(t00, t10, p.a), mix(t01, t11, p.a), p.b);
 }
 // LINEAR fetch at INTEGER texture coordinates: Appendix B.3 (2x2 mean).
 __device__ __forceinline__ float2 linear_at_int(const float2 *t, Geom g, int m, int k) {
@@ -82,8 +105,14 @@ __device__ __forceinline__ float2 linear_at_int(const float2 *t, Geom g, int m, 
 // trips (own velocity, then the four texels), so a one-cell-per-thread kernel is bound by the
 // number of waves in flight, not by bandwidth (measured 3.2 TB/s); each thread therefore
 // issues the loads of ADV_ROWS cells before it consumes any of them.
-constexpr int ADV_ROWS_VEL = 4;   // measured: 1.33 -> 1.23 ms at 16384^2
-constexpr int ADV_ROWS_DENS = 1;  // float4 texels: more rows cost occupancy (1.82 -> 2.08 ms with 4)
+#ifndef ADV_RV
+#define ADV_RV 4
+#endif
+#ifndef ADV_RD
+#define ADV_RD 1
+#endif
+constexpr int ADV_ROWS_VEL = ADV_RV;   // measured: 1.33 -> 1.23 ms at 16384^2
+constexpr int ADV_ROWS_DENS = ADV_RD;  // float4 texels: more rows cost occupancy (1.82 -> 2.08 ms with 4)
 
 #define ADVECT_PROLOGUE                                        \
   const int x = blockIdx.x * BX + threadIdx.x;                 \
@@ -103,9 +132,13 @@ __global__ __launch_bounds__(BX *BY) void k_advect_vel(Geom g, int r0, int r1, V
     v[k] = vin[(size_t)r * g.n + x];
   }
   // Branch-free main path for every cell (the gather is in bounds for any cell thanks to the
-  // clamps), so the 4 x ADV_ROWS texel loads are all in flight together; border cells are
-  // overwritten afterwards on a rarely taken path.
+  // clamps), so the texel loads of all ADV_ROWS cells are in flight together; border cells are
+  // overwritten afterwards on a rarely taken path.  When every lane's four texels lie inside
+  // the domain and the valid rows (all waves but the ones at a border or with a backtrace that
+  // leaves the halo) the gather needs no clamps and two 16-byte loads per cell.
   float2 o[ADV_ROWS];
+  Tap tp[ADV_ROWS];
+  bool inside = true;
 #pragma unroll
   for (int k = 0; k < ADV_ROWS; ++k) {
     const int y = g.ybase + min(rbase + k, r1 - 1);
@@ -113,8 +146,19 @@ __global__ __launch_bounds__(BX *BY) void k_advect_vel(Geom g, int r0, int r1, V
     float py = (float)y - dt * v[k].y;
     px = fmaxf(0.0f, fminf(px, (float)g.n));
     py = fmaxf(0.0f, fminf(py, (float)g.n));
-    const bool interior = x > 0 && x < g.n - 1 && y > 0 && y < g.n - 1;
-    o[k] = bilinear(vin, g, px, py, valid, interior ? flag : nullptr);  // border cells: discarded
+    tp[k] = tap_of(px, py);
+    inside = inside && tap_inside(tp[k], g, valid);
+  }
+  if (__all(inside)) {
+#pragma unroll
+    for (int k = 0; k < ADV_ROWS; ++k) o[k] = bilinear_inside(vin, g, tp[k]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < ADV_ROWS; ++k) {
+      const int y = g.ybase + min(rbase + k, r1 - 1);
+      const bool interior = x > 0 && x < g.n - 1 && y > 0 && y < g.n - 1;
+      o[k] = bilinear(vin, g, tp[k], valid, interior ? flag : nullptr);  // border cells: discarded
+    }
   }
 #pragma unroll
   for (int k = 0; k < ADV_ROWS; ++k) {
@@ -148,6 +192,8 @@ __global__ __launch_bounds__(BX *BY) void k_advect_dens(Geom g, int r0, int r1, 
     v[k] = vel[(size_t)r * g.n + x];
   }
   float4 o[ADV_ROWS];
+  Tap tp[ADV_ROWS];
+  bool inside = true;
 #pragma unroll
   for (int k = 0; k < ADV_ROWS; ++k) {
     const int y = g.ybase + min(rbase + k, r1 - 1);
@@ -155,9 +201,24 @@ __global__ __launch_bounds__(BX *BY) void k_advect_dens(Geom g, int r0, int r1, 
     float py = (float)y - dt * v[k].y;
     px = fmaxf(0.0f, fminf(px, (float)g.n));
     py = fmaxf(0.0f, fminf(py, (float)g.n));
-    const bool interior = x > 0 && x < g.n - 1 && y > 0 && y < g.n - 1;
-    o[k] = bilinear(din, g, px, py, valid, interior ? flag : nullptr);
-    if (!interior) o[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    tp[k] = tap_of(px, py);
+    inside = inside && tap_inside(tp[k], g, valid);
+  }
+  if (__all(inside)) {
+#pragma unroll
+    for (int k = 0; k < ADV_ROWS; ++k) o[k] = bilinear_inside(din, g, tp[k]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < ADV_ROWS; ++k) {
+      const int y = g.ybase + min(rbase + k, r1 - 1);
+      const bool interior = x > 0 && x < g.n - 1 && y > 0 && y < g.n - 1;
+      o[k] = bilinear(din, g, tp[k], valid, interior ? flag : nullptr);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < ADV_ROWS; ++k) {
+    const int y = g.ybase + min(rbase + k, r1 - 1);
+    if (!(x > 0 && x < g.n - 1 && y > 0 && y < g.n - 1)) o[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   }
 #pragma unroll
   for (int k = 0; k < ADV_ROWS; ++k)

@@ -33,7 +33,19 @@ constexpr int WAVES_PER_BLOCK = 4;
 // prefetch were tried against three: no measurable change (0.967 ms either way for the 13-sweep
 // Jacobi launch at 16384^2) at +18 VGPRs and twice the code, so the ring stays at three: the
 // kernels are bound by VALU issue at their occupancy, not by load latency.
-constexpr int RING = 3;
+#ifndef TB_RING
+#define TB_RING 3
+#endif
+constexpr int RING = TB_RING;
+#ifndef TB_ASM
+#define TB_ASM 1
+#endif
+#ifndef TB_XCD
+#define TB_XCD 1
+#endif
+#ifndef TB_STEADY
+#define TB_STEADY 1
+#endif
 
 // value held by lane-1 / lane+1 (DPP wave shift; every lane must be active)
 __device__ __forceinline__ float from_left(float v) {
@@ -66,6 +78,9 @@ __device__ __forceinline__ Row<C> zero_row() {
 }
 
 // Vector load/store of C consecutive floats (16-byte for C=4, 8-byte for C=2).
+// (Non-temporal loads/stores were measured and rejected: the pure access pattern gains 5-10 %
+// in tools/ubench/strip_stream.hip, but the real kernels re-read their x/y halos from L2 and
+// write the dump row over and over: 0.88 -> 1.05 ms with nt loads, 2.2 ms with nt stores too.)
 template <int C>
 __device__ __forceinline__ Row<C> load_row(const float *p) {
   Row<C> r;
@@ -111,15 +126,10 @@ __device__ __forceinline__ Row2<C> zero_row2() {
 template <int C>
 __device__ __forceinline__ Row2<C> load_row2(const float2 *p) {
   Row2<C> r;
-  if constexpr (C == 2) {
-    float4 t = *reinterpret_cast<const float4 *>(p);
-    r.u[0] = t.x; r.w[0] = t.y; r.u[1] = t.z; r.w[1] = t.w;
-  } else {
 #pragma unroll
-    for (int c = 0; c < C; c += 2) {
-      float4 t = reinterpret_cast<const float4 *>(p)[c / 2];
-      r.u[c] = t.x; r.w[c] = t.y; r.u[c + 1] = t.z; r.w[c + 1] = t.w;
-    }
+  for (int c = 0; c < C; c += 2) {
+    const float4 t = reinterpret_cast<const float4 *>(p)[c / 2];
+    r.u[c] = t.x; r.w[c] = t.y; r.u[c + 1] = t.z; r.w[c + 1] = t.w;
   }
   return r;
 }
@@ -137,6 +147,51 @@ __device__ __forceinline__ void store_row2(float2 *p, const Row2<C> &r) {
 // (wave-uniform test); the steady-state instantiation has neither.
 // ---------------------------------------------------------------------------
 
+// Steady-state row rule in hand-placed ISA (2 columns per lane, strip and rows interior).
+// Same operations in the same order as the C++ expression in apply(); what the asm buys is
+// instruction placement: hipcc folds the lane shifts into v_add_f32_dpp whose tied `old`
+// operand lands on a just-written temporary, so nearly every one is preceded by an s_nop (24
+// per 13-level row), and a wave issues only one instruction of any kind per ~7 cycles at the
+// occupancy these kernels run at.  Here the two columns' chains are interleaved and the DPP
+// destination is the (long dead) output slot: no wait states needed.  (DPP hazard: a VALU
+// write of the DPP source in the previous two instructions — the source here is a row produced
+// a whole step earlier; the tied old/vdst is never consumed with bound_ctrl:1 and full masks.
+// tests/test_host_and_build.py scans the emitted ISA for violations.)
+__device__ __forceinline__ void jacobi_row2_asm(float &o0, float &o1, float b0, float b1, float a0,
+                                                float a1, float n0, float n1, float d0, float d1) {
+  asm("v_add_f32_dpp %0, %3, %3 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"  // left(b1) + b1
+      "v_add_f32_dpp %1, %2, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"  // right(b0) + b0
+      "v_add_f32 %0, %0, %4\n\t"
+      "v_add_f32 %1, %1, %5\n\t"
+      "v_add_f32 %0, %0, %6\n\t"
+      "v_add_f32 %1, %1, %7\n\t"
+      "v_sub_f32 %0, %0, %8\n\t"
+      "v_sub_f32 %1, %1, %9\n\t"
+      "v_mul_f32 %0, 0x3e800000, %0\n\t"
+      "v_mul_f32 %1, 0x3e800000, %1"
+      : "=&v"(o0), "=&v"(o1)
+      : "v"(b0), "v"(b1), "v"(a0), "v"(a1), "v"(n0), "v"(n1), "v"(d0), "v"(d1));
+}
+// One plane (u or w) of the diffusion rule, kernel.cu:195.
+__device__ __forceinline__ void diffuse_row2_asm(float &o0, float &o1, float b0, float b1, float a0,
+                                                 float a1, float n0, float n1, float alpha, float beta) {
+  float t0, t1;
+  asm("v_add_f32_dpp %0, %5, %5 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %1, %4, %4 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_mul_f32 %2, %10, %4\n\t"
+      "v_mul_f32 %3, %10, %5\n\t"
+      "v_add_f32 %0, %0, %6\n\t"
+      "v_add_f32 %1, %1, %7\n\t"
+      "v_add_f32 %0, %0, %8\n\t"
+      "v_add_f32 %1, %1, %9\n\t"
+      "v_add_f32 %0, %0, %2\n\t"
+      "v_add_f32 %1, %1, %3\n\t"
+      "v_mul_f32 %0, %11, %0\n\t"
+      "v_mul_f32 %1, %11, %1"
+      : "=&v"(o0), "=&v"(o1), "=&v"(t0), "=&v"(t1)
+      : "v"(b0), "v"(b1), "v"(a0), "v"(a1), "v"(n0), "v"(n1), "s"(alpha), "s"(beta));
+}
+
 // pressureJacobi, kernel.cu:291-324
 template <int C> struct JacobiOp {
   using R = Row<C>;
@@ -147,23 +202,30 @@ template <int C> struct JacobiOp {
   static __device__ __forceinline__ A zero_aux() { return zero_row<C>(); }
   static __device__ __forceinline__ R load(const P &p, size_t off) { return load_row<C>(p.in + off); }
   static __device__ __forceinline__ A load_aux(const P &p, size_t off) { return load_row<C>(p.aux + off); }
-  static __device__ __forceinline__ void store(const P &p, bool real, size_t off, size_t doff, const R &r) {
-    store_row<C>(real ? p.out + off : p.dump + doff, r);
+  static __device__ __forceinline__ Elem *out_ptr(const P &p, bool real, size_t off, size_t doff) {
+    return real ? p.out + off : p.dump + doff;
   }
-  static constexpr bool kLoadsField = true;  // level 0 is read from memory
+  static __device__ __forceinline__ void store_at(Elem *q, const R &r) { store_row<C>(q, r); }
+  static constexpr bool kLoadsField = true;   // level 0 is read from memory
+  static constexpr bool kStoresAux = false;   // the auxiliary rows are only read
 
-  // Divergence rows come from memory through a three-slot ring indexed by the phase.
+  // Divergence rows come from memory through a three-slot ring indexed by the phase; the row a
+  // step consumes is also copied into the pipeline's delay line for the deeper levels.
   template <bool XEDGE> struct Feed {
     A apf[RING];  // in phase J: apf[J + i] = row t - 1 + i, i = 0 .. RING-1
-    template <class PipeT> __device__ __forceinline__ void init(const PipeT &pp, const P &p, int t0) {
+    template <class PipeT> __device__ __forceinline__ void init(PipeT &pp, const P &p, int t0) {
 #pragma unroll
       for (int i = 0; i < RING; ++i) apf[i] = load_aux(p, pp.off(t0 - 1 + i));
     }
-    template <int J, class PipeT> __device__ __forceinline__ A next(const PipeT &pp, const P &p, int t) {
-      A r = apf[J % RING];                                  // row t-1
-      apf[J % RING] = load_aux(p, pp.off(t - 1 + RING));    // refill the freed slot
+    // aux row t-1 (what level 0 needs in step t); `aoff` addresses row t-1+RING
+    template <int J, class PipeT> __device__ __forceinline__ A cur(PipeT &pp, const P &p, size_t aoff) {
+      const A r = apf[J % RING];
+      apf[J % RING] = load_aux(p, aoff);  // refill the freed slot
+      pp.hh(1 - J % 3) = r;
       return r;
     }
+    template <int J, bool YCHK, class PipeT>
+    __device__ __forceinline__ void produce(PipeT &, const P &, int, size_t, float *) {}
   };
 
   template <bool XEDGE, bool YCHK>
@@ -176,6 +238,10 @@ template <int C> struct JacobiOp {
         const float nv = n.v[c], av = a.v[c];  // values, not a select of addresses (keeps SROA)
         o.v[c] = neg_opaque(r <= 0 ? nv : av);
       }
+      return o;
+    }
+    if constexpr (TB_ASM && C == 2 && !XEDGE && !YCHK) {
+      jacobi_row2_asm(o.v[0], o.v[1], b.v[0], b.v[1], a.v[0], a.v[1], n.v[0], n.v[1], d.v[0], d.v[1]);
       return o;
     }
     const float lft = from_left(b.v[C - 1]);
@@ -200,18 +266,23 @@ template <int C> struct JacobiOp {
 template <int C> struct DiffuseOp {
   using R = Row2<C>;
   using A = NoAux;
+  using Elem = float2;
   struct P { const float2 *in; float2 *out; float2 *dump; float alpha, beta; };
   static __device__ __forceinline__ R zero() { return zero_row2<C>(); }
   static __device__ __forceinline__ A zero_aux() { return NoAux{}; }
   static __device__ __forceinline__ R load(const P &p, size_t off) { return load_row2<C>(p.in + off); }
   static __device__ __forceinline__ A load_aux(const P &, size_t) { return NoAux{}; }
-  static __device__ __forceinline__ void store(const P &p, bool real, size_t off, size_t doff, const R &r) {
-    store_row2<C>(real ? p.out + off : p.dump + doff, r);
+  static __device__ __forceinline__ Elem *out_ptr(const P &p, bool real, size_t off, size_t doff) {
+    return real ? p.out + off : p.dump + doff;
   }
+  static __device__ __forceinline__ void store_at(Elem *q, const R &r) { store_row2<C>(q, r); }
   static constexpr bool kLoadsField = true;
+  static constexpr bool kStoresAux = false;
   template <bool XEDGE> struct Feed {  // no auxiliary field
-    template <class PipeT> __device__ __forceinline__ void init(const PipeT &, const P &, int) {}
-    template <int J, class PipeT> __device__ __forceinline__ A next(const PipeT &, const P &, int) { return NoAux{}; }
+    template <class PipeT> __device__ __forceinline__ void init(PipeT &, const P &, int) {}
+    template <int J, class PipeT> __device__ __forceinline__ A cur(PipeT &, const P &, size_t) { return NoAux{}; }
+    template <int J, bool YCHK, class PipeT>
+    __device__ __forceinline__ void produce(PipeT &, const P &, int, size_t, float2 *) {}
   };
 
   template <bool XEDGE, bool YCHK>
@@ -220,6 +291,11 @@ template <int C> struct DiffuseOp {
     if (YCHK && (r <= 0 || r >= N - 1)) return b;  // border copies through, kernel.cu:201-203
     R o;
     const float alpha = p.alpha, beta = p.beta;
+    if constexpr (TB_ASM && C == 2 && !XEDGE && !YCHK) {
+      diffuse_row2_asm(o.u[0], o.u[1], b.u[0], b.u[1], a.u[0], a.u[1], n.u[0], n.u[1], alpha, beta);
+      diffuse_row2_asm(o.w[0], o.w[1], b.w[0], b.w[1], a.w[0], a.w[1], n.w[0], n.w[1], alpha, beta);
+      return o;
+    }
     const float lu = from_left(b.u[C - 1]), lw = from_left(b.w[C - 1]);
     const float ru = from_right(b.u[0]), rw = from_right(b.w[0]);
 #pragma unroll
@@ -247,12 +323,14 @@ template <int C> struct DiffuseOp {
 template <int C> struct JacobiDivOp : JacobiOp<C> {
   using R = Row<C>;
   using A = Row<C>;
+  using Elem = float;
   struct P { const float2 *vel; float *div_out; float *out; float *dump; int n; };
   static __device__ __forceinline__ R load(const P &, size_t) { return zero_row<C>(); }
-  static __device__ __forceinline__ void store(const P &p, bool real, size_t off, size_t doff, const R &r) {
-    store_row<C>(real ? p.out + off : p.dump + doff, r);
+  static __device__ __forceinline__ Elem *out_ptr(const P &p, bool real, size_t off, size_t doff) {
+    return real ? p.out + off : p.dump + doff;
   }
   static constexpr bool kLoadsField = false;
+  static constexpr bool kStoresAux = true;  // divergence row t is stored in step t
 
   template <bool XEDGE, bool YCHK>
   static __device__ __forceinline__ R apply(const R &a, const R &b, const R &n, const A &d, int r,
@@ -262,22 +340,28 @@ template <int C> struct JacobiDivOp : JacobiOp<C> {
 
   template <bool XEDGE> struct Feed {
     Row2<C> vpf[RING];  // velocity ring: in phase J slot J + i holds row t + 1 + i
-    Row2<C> va, vb;  // velocity rows t-1 and t
-    A dcur;          // divergence row t-1
-    template <class PipeT> __device__ __forceinline__ void init(const PipeT &pp, const P &p, int t0) {
-      va = zero_row2<C>();
+    float wa[C];        // y-velocity of row t-1
+    Row2<C> vb;         // velocity row t
+    template <class PipeT> __device__ __forceinline__ void init(PipeT &pp, const P &p, int t0) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) wa[c] = 0.0f;
       vb = load_row2<C>(p.vel + pp.off(t0));
 #pragma unroll
       for (int i = 0; i < RING; ++i) vpf[i] = load_row2<C>(p.vel + pp.off(t0 + 1 + i));
-      dcur = zero_row<C>();
     }
-    template <int J, class PipeT> __device__ __forceinline__ A next(const PipeT &pp, const P &p, int t) {
-      const A ret = dcur;                               // divergence row t-1
-      const Row2<C> vc = vpf[J % RING];                          // velocity row t+1
-      vpf[J % RING] = load_row2<C>(p.vel + pp.off(t + 1 + RING));  // refill the freed slot
+    // divergence row t-1 was produced by the previous step straight into the slot read here
+    template <int J, class PipeT> __device__ __forceinline__ A cur(PipeT &pp, const P &, size_t) {
+      return pp.hh(1 - J % 3);
+    }
+    // divergence row t from velocity rows t-1, t, t+1; `voff` addresses velocity row t+1+RING,
+    // `dst` is where divergence row t is stored (its real place or the dump row)
+    template <int J, bool YCHK, class PipeT>
+    __device__ __forceinline__ void produce(PipeT &pp, const P &p, int t, size_t voff, float *dst) {
+      const Row2<C> vc = vpf[J % RING];                 // velocity row t+1
+      vpf[J % RING] = load_row2<C>(p.vel + voff);       // refill the freed slot
       A d;
       const int N = pp.g.n;
-      if (t <= 0 || t >= N - 1) {  // wave-uniform: border rows, kernel.cu:287
+      if (YCHK && (t <= 0 || t >= N - 1)) {  // wave-uniform: border rows, kernel.cu:287
         d = zero_row<C>();
       } else {
         const float lu = from_left(vb.u[C - 1]);
@@ -286,7 +370,7 @@ template <int C> struct JacobiDivOp : JacobiOp<C> {
         for (int c = 0; c < C; ++c) {
           const float uL = c > 0 ? vb.u[c - 1] : lu;
           const float uR = c < C - 1 ? vb.u[c + 1] : ru;
-          float v = 0.5f * ((uR - uL) + (vc.w[c] - va.w[c]));  // kernel.cu:282
+          float v = 0.5f * ((uR - uL) + (vc.w[c] - wa[c]));  // kernel.cu:282
           if (XEDGE) {
             const int x = pp.x0 + c;
             if (x == 0 || x == N - 1) v = 0.0f;  // kernel.cu:287
@@ -294,14 +378,11 @@ template <int C> struct JacobiDivOp : JacobiOp<C> {
           d.v[c] = v;
         }
       }
-      // divergence row t is part of the state (later launches, fluid_read): store it for the
-      // rows and columns this wave owns, to the dump row otherwise
-      const bool real = pp.st_ok && t >= pp.ya && t < pp.yb;
-      store_row<C>(real ? p.div_out + pp.off(t) : p.dump + (size_t)p.n + pp.xc, d);
-      va = vb;
+      store_row<C>(dst, d);
+#pragma unroll
+      for (int c = 0; c < C; ++c) wa[c] = vb.w[c];
       vb = vc;
-      dcur = d;
-      return ret;
+      pp.hh(J % 3 == 2 ? -2 : -(J % 3)) = d;  // where the next step's cur() reads it (after the shift if J == 2)
     }
   };
 };
@@ -313,18 +394,27 @@ template <int C> struct JacobiDivOp : JacobiOp<C> {
 // writes the new row straight into slot (J+2) mod 3, so rows never move
 // between registers.  The time loop is unrolled by 3 so every slot index is a
 // compile-time constant.
+//
+// The auxiliary field (divergence) is needed by level l at row t-l-1: a delay
+// line.  h[] holds it with hh(j) = row tg - j (tg = first step of the current
+// group of three), so level l >= 1 reads hh(l+1-J) in phase J — static indices
+// again — and the line shifts by three rows once per group instead of by one
+// row per step (a third of the register moves).
 // ---------------------------------------------------------------------------
 template <class Op, int K, bool XEDGE> struct Pipe {
   using R = typename Op::R;
   using A = typename Op::A;
   using P = typename Op::P;
+  using Elem = typename Op::Elem;
   R s[K + 1][3];
-  A dv[K];   // dv[l] = aux row needed by level l+1 this step (row t-l-1)
-  R pf[RING];  // prefetch ring: in phase J, pf[J + i] = level-0 row t + i
+  A h[K + 3];   // hh(j), j = -2 .. K
+  R pf[RING];   // prefetch ring: in phase J, pf[J + i] = level-0 row t + i
   typename Op::template Feed<XEDGE> feed;  // where the auxiliary rows come from
   Geom g;
   int x0, xc, ya, yb;  // xc: x0 clamped into the domain (address of this lane's loads)
   bool st_ok;
+
+  __device__ __forceinline__ A &hh(int j) { return h[j + 2]; }
 
   // Every load and store below is UNCONDITIONAL.  A predicated or branched-around memory
   // operation makes hipcc's s_waitcnt placement assume it may not have been issued, and the
@@ -337,63 +427,139 @@ template <class Op, int K, bool XEDGE> struct Pipe {
     const int r = min(max(t - g.ybase, 0), g.L - 1);
     return (size_t)r * g.n + xc;
   }
-  __device__ __forceinline__ R ld(const P &p, int t) const { return Op::load(p, off(t)); }
 
   __device__ __forceinline__ void init(const P &p, int t0) {
 #pragma unroll
     for (int l = 0; l < K; ++l) {
 #pragma unroll
       for (int j = 0; j < 3; ++j) s[l][j] = Op::zero();
-      dv[l] = Op::zero_aux();
     }
 #pragma unroll
-    for (int i = 0; i < RING; ++i) pf[i] = ld(p, t0 + i);
+    for (int j = 0; j < K + 3; ++j) h[j] = Op::zero_aux();
+    if constexpr (Op::kLoadsField) {
+#pragma unroll
+      for (int i = 0; i < RING; ++i) pf[i] = Op::load(p, off(t0 + i));
+    }
     feed.init(*this, p, t0);
   }
 
+  __device__ __forceinline__ void shift_aux() {
+#pragma unroll
+    for (int j = K; j >= 1; --j) hh(j) = hh(j - 3);
+  }
+
   template <int J, bool YCHK>
-  __device__ __forceinline__ R levels(const P &p, int t) {
+  __device__ __forceinline__ R levels(const P &p, int t, const A &cur) {
     R fin = Op::zero();
 #pragma unroll
     for (int l = 0; l < K; ++l) {
-      R o = Op::template apply<XEDGE, YCHK>(s[l][J % 3], s[l][(J + 1) % 3], s[l][(J + 2) % 3], dv[l],
+      A d = cur;  // a copy of the value (never a select between two rows' addresses)
+      if (l > 0) d = hh(l + 1 - J % 3);
+      R o = Op::template apply<XEDGE, YCHK>(s[l][J % 3], s[l][(J + 1) % 3], s[l][(J + 2) % 3], d,
                                             t - l - 1, x0, g.n, p);
       if (l + 1 < K) s[l + 1][(J + 2) % 3] = o; else fin = o;
     }
     return fin;
   }
 
-  // One time step.  Nothing loop-carried changes register: the rings are indexed by the phase,
-  // so the loads issued here are first touched RING steps later (counted vmcnt, not vmcnt(0)).
+  // One time step, any row.  Nothing loop-carried changes register: the rings are indexed by the
+  // phase, so the loads issued here are first touched RING steps later (counted vmcnt).
   template <int J>
   __device__ __forceinline__ void step(const P &p, int t) {
-#pragma unroll
-    for (int l = K - 1; l > 0; --l) dv[l] = dv[l - 1];
-    dv[0] = feed.template next<J>(*this, p, t);  // aux row t-1
+    if (J % 3 == 0) shift_aux();
+    const A cur = feed.template cur<J>(*this, p, off(t - 1 + RING));  // aux row t-1
     if constexpr (Op::kLoadsField) {
-      s[0][(J + 2) % 3] = pf[J % RING];  // level 0, row t
-      pf[J % RING] = ld(p, t + RING);    // refill the freed slot: RING rows of prefetch
+      s[0][(J + 2) % 3] = pf[J % RING];          // level 0, row t
+      pf[J % RING] = Op::load(p, off(t + RING));  // refill the freed slot: RING rows of prefetch
+    }
+    if constexpr (Op::kStoresAux) {
+      const bool areal = st_ok && t >= ya && t < yb;
+      feed.template produce<J, true>(*this, p, t, off(t + 1 + RING),
+                                     areal ? p.div_out + off(t) : p.dump + (size_t)g.n + xc);
     }
     R fin;
-    if (t - K >= 1 && t - 1 <= g.n - 2) fin = levels<J, false>(p, t);  // every level's row is y-interior
-    else fin = levels<J, true>(p, t);
+    if (t - K >= 1 && t - 1 <= g.n - 2) fin = levels<J, false>(p, t, cur);  // every level's row is y-interior
+    else fin = levels<J, true>(p, t, cur);
     const int ro = t - K;  // level K row just produced
-    Op::store(p, st_ok && ro >= ya && ro < yb, off(ro), (size_t)xc, fin);
+    Op::store_at(Op::out_ptr(p, st_ok && ro >= ya && ro < yb, off(ro), (size_t)xc), fin);
+  }
+
+  // Steady state: every level's row is y-interior, the produced row (and divergence row) is one
+  // this wave stores, and no load needs clamping — the row addresses are a uniform offset that
+  // advances by one row per step plus this lane's column, the store pointers advance by a
+  // per-lane stride (zero for the lanes that write the dump row).
+  struct Steady {
+    size_t ro;       // (t - ybase) * n, uniform
+    Elem *sp;        // where this lane stores row t-K
+    float *dp;       // where it stores auxiliary row t (kStoresAux)
+    size_t sstride;  // n for storing lanes, 0 for dump lanes
+  };
+  __device__ __forceinline__ void steady_init(const P &p, int t, Steady &st) const {
+    st.ro = (size_t)(t - g.ybase) * g.n;
+    st.sstride = st_ok ? (size_t)g.n : 0;
+    st.sp = Op::out_ptr(p, st_ok, (size_t)(t - K - g.ybase) * g.n + xc, (size_t)xc);
+    st.dp = nullptr;
+    if constexpr (Op::kStoresAux) st.dp = st_ok ? p.div_out + st.ro + xc : p.dump + (size_t)g.n + xc;
+  }
+  template <int J>
+  __device__ __forceinline__ void steady_step(const P &p, int t, Steady &st) {
+    if (J % 3 == 0) shift_aux();
+    const size_t n = g.n;
+    const A cur = feed.template cur<J>(*this, p, st.ro + (RING - 1) * n + (unsigned)xc);
+    if constexpr (Op::kLoadsField) {
+      s[0][(J + 2) % 3] = pf[J % RING];
+      pf[J % RING] = Op::load(p, st.ro + RING * n + (unsigned)xc);
+    }
+    if constexpr (Op::kStoresAux)
+      feed.template produce<J, false>(*this, p, t, st.ro + (RING + 1) * n + (unsigned)xc, st.dp);
+    const R fin = levels<J, false>(p, t, cur);
+    Op::store_at(st.sp, fin);
+    st.sp += st.sstride;
+    if constexpr (Op::kStoresAux) st.dp += st.sstride;
+    st.ro += n;
   }
 
   __device__ __forceinline__ void run(const P &p) {
     const int t0 = ya - K, t1 = yb + K;
     init(p, t0);
-    static_assert(RING == 3 || RING == 6, "the unrolled body below handles RING 3 and 6");
-    for (int t = t0; t < t1; t += RING) {  // up to RING-1 surplus steps: loads are clamped, stores dumped
-      step<0>(p, t);
-      step<1>(p, t + 1);
-      step<2>(p, t + 2);
-      if constexpr (RING == 6) {
-        step<3>(p, t + 3);
-        step<4>(p, t + 4);
-        step<5>(p, t + 5);
+    static_assert(RING == 3 || RING == 6, "the time loop is unrolled by a multiple of the slot period");
+    // steady window [lo, hi] of steps, then the groups of three that lie inside it
+    const int lo = max(ya + K, K + 1);
+    const int hi = min(min((Op::kStoresAux ? yb : yb + K) - 1, g.n - 1), g.ybase + g.L - 2 - RING);
+    const int tsa = t0 + RING * ((lo - t0 + RING - 1) / RING);
+    const int tea = hi - (RING - 1) >= tsa ? t0 + RING * ((hi - (RING - 1) - t0) / RING) : tsa - RING;
+    Steady st;
+    steady_init(p, tsa, st);
+    // general steps up to the steady window, the window, general steps to the end: one copy of
+    // the general loop's code, run twice (up to RING-1 surplus steps at the end: loads are
+    // clamped, stores dumped)
+    int t = t0;
+    int gend = TB_STEADY && tea >= tsa ? min(tsa, t1) : t1;
+#pragma nounroll
+    for (int pass = 0; pass < 2; ++pass) {
+      for (; t < gend; t += RING) {
+        step<0>(p, t);
+        step<1>(p, t + 1);
+        step<2>(p, t + 2);
+        if constexpr (RING == 6) {
+          step<3>(p, t + 3);
+          step<4>(p, t + 4);
+          step<5>(p, t + 5);
+        }
       }
+      if (pass == 0 && gend < t1) {
+        for (; t <= tea; t += RING) {
+          steady_step<0>(p, t, st);
+          steady_step<1>(p, t + 1, st);
+          steady_step<2>(p, t + 2, st);
+          if constexpr (RING == 6) {
+            steady_step<3>(p, t + 3, st);
+            steady_step<4>(p, t + 4, st);
+            steady_step<5>(p, t + 5, st);
+          }
+        }
+      }
+      gend = t1;
     }
   }
 };
@@ -403,14 +569,24 @@ __device__ __forceinline__ void tb_kernel_body(Geom g, int r0, int r1, int chunk
                                                const typename Op::P &p) {
   using SG = StripGeom<K, C>;
   const int lane = threadIdx.x & (WAVE - 1);
-  const int strip = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+  // Workgroups are handed to the 8 XCDs round-robin by linear id; remap so that each XCD (own L2)
+  // works on a contiguous run of blocks: neighbouring strips share halo columns, consecutive
+  // chunks share halo rows.
+  // (1-D grid of 8 * ceil(blocks / 8) workgroups, tb_grid below.)
+  const int gx = ((g.n + SG::VW - 1) / SG::VW + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+  const int nb = gx * ((r1 - r0 + chunk - 1) / chunk);
+  int id = blockIdx.x;
+  if (TB_XCD) id = (id % 8) * ((nb + 7) / 8) + id / 8;
+  if (id >= nb) return;  // whole block: the padding of the grid
+  const int bx = id % gx, by = id / gx;
+  const int strip = bx * WAVES_PER_BLOCK + (threadIdx.x >> 6);
   const int xs = strip * SG::VW;
   if (xs >= g.n) return;  // whole wave
   const int x0 = xs - SG::HX + lane * C;
   const bool in_dom = x0 >= 0 && x0 < g.n;  // n % C == 0: a lane's columns are all in or all out
   const bool st_ok = in_dom && lane * C >= SG::HX && lane * C < SG::HX + SG::VW;
   const int xc = min(max(x0, 0), g.n - C);
-  const int ya = g.ybase + r0 + blockIdx.y * chunk;
+  const int ya = g.ybase + r0 + by * chunk;
   const int yb = min(ya + chunk, g.ybase + r1);
   const bool xedge = xs == 0 || xs + SG::VW + SG::HX >= g.n;  // wave-uniform
   if (xedge) {
@@ -454,7 +630,8 @@ template <int K, int C>
 dim3 tb_grid(Geom g, int r0, int r1, int chunk) {
   using SG = StripGeom<K, C>;
   const int strips = (g.n + SG::VW - 1) / SG::VW;
-  return dim3((strips + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK, (r1 - r0 + chunk - 1) / chunk);
+  const int nb = ((strips + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK) * ((r1 - r0 + chunk - 1) / chunk);
+  return dim3((nb + 7) / 8 * 8);  // see tb_kernel_body: padded so the XCD remap is a bijection
 }
 
 template <int K, int C>
@@ -481,32 +658,39 @@ void diffuse_tb_launch(hipStream_t s, Geom g, int r0, int r1, int chunk, float a
 
 }  // namespace
 
-// Instantiated sweep counts.  Wide lanes (4 columns) stop at 10 sweeps (VGPR budget); the
-// 2-column form goes to 20 (about 200 VGPRs, two waves per SIMD).
-#define TB_DISPATCH_K(FN, C_, ...)                    \
-  switch (k) {                                        \
-    case 1: FN<1, C_>(__VA_ARGS__); return true;      \
-    case 2: FN<2, C_>(__VA_ARGS__); return true;      \
-    case 4: FN<4, C_>(__VA_ARGS__); return true;      \
-    case 5: FN<5, C_>(__VA_ARGS__); return true;      \
-    case 8: FN<8, C_>(__VA_ARGS__); return true;      \
-    case 10: FN<10, C_>(__VA_ARGS__); return true;    \
-    default: break;                                   \
+// Instantiated sweep counts.  Four columns per lane stop at 5 sweeps, two columns at 10
+// (diffusion, two planes) / 14 (pressure): beyond that the pipeline no longer fits 256 VGPRs.
+#define TB_DISPATCH_K4(FN, ...)                      \
+  switch (k) {                                       \
+    case 1: FN<1, 4>(__VA_ARGS__); return true;      \
+    case 2: FN<2, 4>(__VA_ARGS__); return true;      \
+    case 4: FN<4, 4>(__VA_ARGS__); return true;      \
+    case 5: FN<5, 4>(__VA_ARGS__); return true;      \
+    default: return false;                           \
   }
-#define TB_DISPATCH_K_DEEP(FN, C_, ...)               \
-  switch (k) {                                        \
-    case 13: FN<13, C_>(__VA_ARGS__); return true;    \
-    case 14: FN<14, C_>(__VA_ARGS__); return true;    \
-    case 20: FN<20, C_>(__VA_ARGS__); return true;    \
-    default: break;                                   \
+#define TB_DISPATCH_K2(FN, ...)                      \
+  switch (k) {                                       \
+    case 1: FN<1, 2>(__VA_ARGS__); return true;      \
+    case 2: FN<2, 2>(__VA_ARGS__); return true;      \
+    case 4: FN<4, 2>(__VA_ARGS__); return true;      \
+    case 5: FN<5, 2>(__VA_ARGS__); return true;      \
+    case 8: FN<8, 2>(__VA_ARGS__); return true;      \
+    case 10: FN<10, 2>(__VA_ARGS__); return true;    \
+    default: break;                                  \
+  }
+#define TB_DISPATCH_K2_DEEP(FN, ...)                 \
+  switch (k) {                                       \
+    case 13: FN<13, 2>(__VA_ARGS__); return true;    \
+    case 14: FN<14, 2>(__VA_ARGS__); return true;    \
+    default: break;                                  \
   }
 
 bool tb_supported(int n, int cols) { return (cols == 2 || cols == 4) && n % cols == 0 && n >= 8; }
 bool tb_has_k(int k, int cols, bool float2_field) {
   switch (k) {
-    case 1: case 2: case 4: case 5: case 8: return true;
-    case 10: return !(float2_field && cols == 4);  // diffusion 10 x 4 columns overflows the VGPR file
-    case 13: case 14: case 20: return cols == 2 && !float2_field;
+    case 1: case 2: case 4: case 5: return true;
+    case 8: case 10: return cols == 2;
+    case 13: case 14: return cols == 2 && !float2_field;
     default: return false;
   }
 }
@@ -515,9 +699,9 @@ bool launch_jacobi_tb(hipStream_t s, Geom g, int r0, int r1, int k, int cols, in
                       const float *pin, const float *div, float *pout, void *dump) {
   if (r1 <= r0) return true;
   if (!tb_supported(g.n, cols) || chunk < 1 || !tb_has_k(k, cols, false)) return false;
-  if (cols == 4) { TB_DISPATCH_K(jacobi_tb_launch, 4, s, g, r0, r1, chunk, pin, div, pout, dump) return false; }
-  TB_DISPATCH_K(jacobi_tb_launch, 2, s, g, r0, r1, chunk, pin, div, pout, dump)
-  TB_DISPATCH_K_DEEP(jacobi_tb_launch, 2, s, g, r0, r1, chunk, pin, div, pout, dump)
+  if (cols == 4) TB_DISPATCH_K4(jacobi_tb_launch, s, g, r0, r1, chunk, pin, div, pout, dump)
+  TB_DISPATCH_K2(jacobi_tb_launch, s, g, r0, r1, chunk, pin, div, pout, dump)
+  TB_DISPATCH_K2_DEEP(jacobi_tb_launch, s, g, r0, r1, chunk, pin, div, pout, dump)
   return false;
 }
 
@@ -525,9 +709,9 @@ bool launch_jacobi_div_tb(hipStream_t s, Geom g, int r0, int r1, int k, int cols
                           const float2 *vel, float *div_out, float *pout, void *dump) {
   if (r1 <= r0) return true;
   if (!tb_supported(g.n, cols) || chunk < 1 || !tb_has_k(k, cols, false)) return false;
-  if (cols == 4) { TB_DISPATCH_K(jacobi_div_tb_launch, 4, s, g, r0, r1, chunk, vel, div_out, pout, dump) return false; }
-  TB_DISPATCH_K(jacobi_div_tb_launch, 2, s, g, r0, r1, chunk, vel, div_out, pout, dump)
-  TB_DISPATCH_K_DEEP(jacobi_div_tb_launch, 2, s, g, r0, r1, chunk, vel, div_out, pout, dump)
+  if (cols == 4) TB_DISPATCH_K4(jacobi_div_tb_launch, s, g, r0, r1, chunk, vel, div_out, pout, dump)
+  TB_DISPATCH_K2(jacobi_div_tb_launch, s, g, r0, r1, chunk, vel, div_out, pout, dump)
+  TB_DISPATCH_K2_DEEP(jacobi_div_tb_launch, s, g, r0, r1, chunk, vel, div_out, pout, dump)
   return false;
 }
 
@@ -535,16 +719,7 @@ bool launch_diffuse_tb(hipStream_t s, Geom g, int r0, int r1, int k, int cols, i
                        float alpha, float beta, const float2 *vin, float2 *vout, void *dump) {
   if (r1 <= r0) return true;
   if (!tb_supported(g.n, cols) || chunk < 1 || !tb_has_k(k, cols, true)) return false;
-  if (cols == 4) {
-    switch (k) {  // no K = 10 here
-      case 1: diffuse_tb_launch<1, 4>(s, g, r0, r1, chunk, alpha, beta, vin, vout, dump); return true;
-      case 2: diffuse_tb_launch<2, 4>(s, g, r0, r1, chunk, alpha, beta, vin, vout, dump); return true;
-      case 4: diffuse_tb_launch<4, 4>(s, g, r0, r1, chunk, alpha, beta, vin, vout, dump); return true;
-      case 5: diffuse_tb_launch<5, 4>(s, g, r0, r1, chunk, alpha, beta, vin, vout, dump); return true;
-      case 8: diffuse_tb_launch<8, 4>(s, g, r0, r1, chunk, alpha, beta, vin, vout, dump); return true;
-      default: return false;
-    }
-  }
-  TB_DISPATCH_K(diffuse_tb_launch, 2, s, g, r0, r1, chunk, alpha, beta, vin, vout, dump)
+  if (cols == 4) TB_DISPATCH_K4(diffuse_tb_launch, s, g, r0, r1, chunk, alpha, beta, vin, vout, dump)
+  TB_DISPATCH_K2(diffuse_tb_launch, s, g, r0, r1, chunk, alpha, beta, vin, vout, dump)
   return false;
 }
