@@ -228,7 +228,7 @@ void enq_vorticity(fluid_ctx *c) {
 
 // projection()  kernel.cu:604-662.  The projected velocity is produced on the owned rows;
 // it needs p^J one row beyond, hence p^j on 1 + J - j rows beyond and the divergence on J.
-void enq_project(fluid_ctx *c) {
+void enq_project(fluid_ctx *c, bool with_density = false) {
   const double cells = (double)cells_owned(c);
   const int J = c->prm.pressure_iters;
   const bool tb = use_tb(c, c->tb_cj);
@@ -270,6 +270,18 @@ void enq_project(fluid_ctx *c) {
       c->pin ^= 1;
     }
   }
+  if (with_density) {
+    // + simulateDensityAdvection() kernel.cu:664-685 on the same rows (see enq_step)
+    ProfScope p(c, K_PROJECT_ADVECT_DENS, 60.0 * cells);
+    const Range r = widened(c, 0);
+    const Range valid = c->slab ? widened(c, c->halo_dens) : Range{0, c->g.L};
+    launch_project_advect_dens(c->stream, c->g, r.r0, r.r1, valid.r0, valid.r1, c->prm.dt,
+                               c->vel[c->vin], c->prs[c->pin], c->vel[c->vin ^ 1], c->dens[c->din],
+                               c->dens[c->din ^ 1], c->halo_flag);
+    c->vin ^= 1;
+    c->din ^= 1;
+    return;
+  }
   {
     ProfScope p(c, K_PROJECT, 20.0 * cells);
     const Range r = widened(c, 0);
@@ -297,7 +309,11 @@ void enq_step(fluid_ctx *c, int parts) {
     enq_advect_velocity(c, m_diff + c->prm.diffusion_iters);
     enq_diffuse(c, m_diff);
     if (c->prm.flags & FLUID_FLAG_VORTICITY) enq_vorticity(c);  // kernel.cu:705
-    enq_project(c);
+    // When the whole step is enqueued at once, the gradient subtraction and the density
+    // advection (both over the owned rows) run as one kernel.
+    const bool fuse = (parts & FLUID_PART_DENSITY) && !(c->prm.flags & FLUID_FLAG_UNFUSED);
+    enq_project(c, fuse);
+    if (fuse) return;
   }
   if (parts & FLUID_PART_DENSITY) enq_advect_density(c);
 }
@@ -436,14 +452,15 @@ int fluid_init(fluid_ctx **out, const fluid_params *p) {
   // tuning knobs (defaults chosen from measurements); results do not depend on them
   // Plan by owned cells, from sweeps on MI355X (tools/tb_sweep.py, tools/small_sweep.py):
   //   <= ~1024^2 : launch/latency bound -> short pipelines, as many waves as possible
-  //   ~2048^2    : 5 sweeps per launch
+  //   ~2048^2    : 8 sweeps per launch
   //   ~4096^2    : fields sit in the Infinity Cache -> 10 Jacobi / 5 diffusion sweeps per launch
   //   >= 8192^2  : HBM round trips dominate -> 13-14 Jacobi / 10 diffusion sweeps per launch,
   //                twice the waves (shorter chunks even out the tail of the launch)
   const long long owned = (long long)prm.n * si.rows;
-  if (owned < (1ll << 21)) { c->tb_kj = 5; c->tb_minchunk = 1; }
-  else if (owned < (1ll << 23)) { c->tb_kj = 5; }
-  else if (owned >= (1ll << 26)) { c->tb_kd = 10; c->tb_kj = 14; c->tb_waves = 16384; c->tb_minchunk = 1; }
+  if (owned < (1ll << 21)) { c->tb_kj = 4; c->tb_minchunk = 1; }
+  else if (owned < (1ll << 23)) { c->tb_kj = 8; c->tb_minchunk = 1; }
+  else if (owned < (1ll << 26)) { c->tb_waves = 4096; }
+  else { c->tb_kd = 10; c->tb_kj = 14; c->tb_waves = 16384; c->tb_minchunk = 1; }
   c->tb_kj = env_int("FLUID_TB_KJ", c->tb_kj);
   c->tb_kd = env_int("FLUID_TB_KD", c->tb_kd);
   c->tb_cj = env_int("FLUID_TB_CJ", c->tb_cj);

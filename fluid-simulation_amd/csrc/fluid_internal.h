@@ -27,6 +27,7 @@ enum KernelId {
   K_DIFFUSE_TB,   // temporally blocked diffusion
   K_JACOBI_TB,    // temporally blocked Jacobi
   K_JACOBI_DIV_TB,  // divergence + pressure clear + first Jacobi launch
+  K_PROJECT_ADVECT_DENS,  // gradient subtraction + density advection in one pass
   K_COUNT
 };
 extern const char *const kKernelNames[K_COUNT];
@@ -45,6 +46,9 @@ void launch_jacobi(hipStream_t s, Geom g, int r0, int r1, const float *pin, cons
                    float *pout);
 void launch_project(hipStream_t s, Geom g, int r0, int r1, const float2 *vin, const float *p,
                     float2 *vout);
+void launch_project_advect_dens(hipStream_t s, Geom g, int r0, int r1, int vlo, int vhi, float dt,
+                                const float2 *vin, const float *p, float2 *vout, const float4 *din,
+                                float4 *dout, int *flag);
 void launch_advect_dens(hipStream_t s, Geom g, int r0, int r1, int vlo, int vhi, float dt,
                         const float2 *vel, const float4 *din, float4 *dout, int *halo_flag);
 void launch_add_force(hipStream_t s, Geom g, int r0, int r1, float dt, float radius, float sx,

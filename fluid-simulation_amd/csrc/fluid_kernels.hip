@@ -18,7 +18,8 @@
 
 const char *const kKernelNames[K_COUNT] = {
     "k_advect_vel", "k_diffuse",   "k_divergence",    "k_jacobi",     "k_project", "k_advect_dens",
-    "k_add_force",  "k_vorticity", "k_add_vorticity", "k_diffuse_tb", "k_jacobi_tb", "k_jacobi_div_tb"};
+    "k_add_force",  "k_vorticity", "k_add_vorticity", "k_diffuse_tb", "k_jacobi_tb", "k_jacobi_div_tb",
+    "k_project_advect_dens"};
 
 namespace {
 
@@ -276,24 +277,50 @@ __global__ __launch_bounds__(BX *BY) void k_jacobi(Geom g, int r0, int r1,
 }
 
 // kernel.cu:326-355
+__device__ __forceinline__ float2 project_cell(Geom g, int x, int y, int r, size_t id, bool interior,
+                                               const float2 *__restrict__ vin,
+                                               const float *__restrict__ p) {
+  if (interior) {
+    float pL = p[id - 1], pR = p[id + 1], pB = p[id - g.n], pT = p[id + g.n];
+    float2 v = vin[id];
+    return make_float2(v.x - (pR - pL), v.y - (pT - pB));
+  }
+  float2 o = make_float2(0.0f, 0.0f);
+  const int xp = min(x + 1, g.n - 1);  // clamp-to-edge of x+1 (kernel.cu:352-353)
+  if (x == 0) o = neg(vin[id + 1]);
+  if (x == g.n - 1) o = neg(vin[id - 1]);
+  if (y == 0) o = neg(vin[(size_t)(r + 1) * g.n + xp]);
+  if (y == g.n - 1) o = neg(vin[(size_t)(r - 1) * g.n + xp]);
+  return o;
+}
 __global__ __launch_bounds__(BX *BY) void k_project(Geom g, int r0, int r1,
                                                      const float2 *__restrict__ vin,
                                                      const float *__restrict__ p,
                                                      float2 *__restrict__ vout) {
   CELL_PROLOGUE
-  if (interior) {
-    float pL = p[id - 1], pR = p[id + 1], pB = p[id - g.n], pT = p[id + g.n];
-    float2 v = vin[id];
-    vout[id] = make_float2(v.x - (pR - pL), v.y - (pT - pB));
-  } else {
-    float2 o = make_float2(0.0f, 0.0f);
-    const int xp = min(x + 1, g.n - 1);  // clamp-to-edge of x+1 (kernel.cu:352-353)
-    if (x == 0) o = neg(vin[id + 1]);
-    if (x == g.n - 1) o = neg(vin[id - 1]);
-    if (y == 0) o = neg(vin[(size_t)(r + 1) * g.n + xp]);
-    if (y == g.n - 1) o = neg(vin[(size_t)(r - 1) * g.n + xp]);
-    vout[id] = o;
-  }
+  vout[id] = project_cell(g, x, y, r, id, interior, vin, p);
+}
+
+// projection (kernel.cu:326-355) and density advection (kernel.cu:142-165) of the same cell in one
+// pass: the density backtrace starts from the projected velocity of its own cell only, so the
+// value just computed is used instead of being written out and read back (8 B/cell less).
+__global__ __launch_bounds__(BX *BY) void k_project_advect_dens(
+    Geom g, int r0, int r1, Valid valid, float dt, const float2 *__restrict__ vin,
+    const float *__restrict__ p, float2 *__restrict__ vout, const float4 *__restrict__ din,
+    float4 *__restrict__ dout, int *flag) {
+  CELL_PROLOGUE
+  const float2 v = project_cell(g, x, y, r, id, interior, vin, p);
+  vout[id] = v;
+  float px = (float)x - dt * v.x;
+  float py = (float)y - dt * v.y;
+  px = fmaxf(0.0f, fminf(px, (float)g.n));
+  py = fmaxf(0.0f, fminf(py, (float)g.n));
+  const Tap tp = tap_of(px, py);
+  float4 o;
+  if (__all(tap_inside(tp, g, valid))) o = bilinear_inside(din, g, tp);
+  else o = bilinear(din, g, tp, valid, interior ? flag : nullptr);
+  if (!interior) o = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  dout[id] = o;
 }
 
 // kernel.cu:357-383 (every cell, border included)
@@ -378,6 +405,13 @@ void launch_project(hipStream_t s, Geom g, int r0, int r1, const float2 *vin, co
                     float2 *vout) {
   if (r1 <= r0) return;
   hipLaunchKernelGGL(k_project, grid_for(g, r0, r1), kBlock, 0, s, g, r0, r1, vin, p, vout);
+}
+void launch_project_advect_dens(hipStream_t s, Geom g, int r0, int r1, int vlo, int vhi, float dt,
+                                const float2 *vin, const float *p, float2 *vout, const float4 *din,
+                                float4 *dout, int *flag) {
+  if (r1 <= r0) return;
+  hipLaunchKernelGGL(k_project_advect_dens, grid_for(g, r0, r1), kBlock, 0, s, g, r0, r1, Valid{vlo, vhi}, dt,
+                     vin, p, vout, din, dout, flag);
 }
 void launch_advect_dens(hipStream_t s, Geom g, int r0, int r1, int vlo, int vhi, float dt,
                         const float2 *vel, const float4 *din, float4 *dout, int *flag) {

@@ -208,6 +208,10 @@ template <int C> struct JacobiOp {
   static __device__ __forceinline__ void store_at(Elem *q, const R &r) { store_row<C>(q, r); }
   static constexpr bool kLoadsField = true;   // level 0 is read from memory
   static constexpr bool kStoresAux = false;   // the auxiliary rows are only read
+  // The separate steady-state loop (Pipe::steady_step) costs ~20 VGPRs.  The pressure launches are
+  // bound by their memory pattern, not by instruction issue (measured: 0.876 ms with it, 0.866
+  // without at 16384^2; 0.086 vs 0.077 at 4096^2 where the registers cost a wave per SIMD).
+  static constexpr bool kSteady = false;
 
   // Divergence rows come from memory through a three-slot ring indexed by the phase; the row a
   // step consumes is also copied into the pipeline's delay line for the deeper levels.
@@ -278,6 +282,7 @@ template <int C> struct DiffuseOp {
   static __device__ __forceinline__ void store_at(Elem *q, const R &r) { store_row2<C>(q, r); }
   static constexpr bool kLoadsField = true;
   static constexpr bool kStoresAux = false;
+  static constexpr bool kSteady = true;  // two planes per column: issue-bound, 1.14 -> 1.06 ms at 16384^2
   template <bool XEDGE> struct Feed {  // no auxiliary field
     template <class PipeT> __device__ __forceinline__ void init(PipeT &, const P &, int) {}
     template <int J, class PipeT> __device__ __forceinline__ A cur(PipeT &, const P &, size_t) { return NoAux{}; }
@@ -331,6 +336,7 @@ template <int C> struct JacobiDivOp : JacobiOp<C> {
   }
   static constexpr bool kLoadsField = false;
   static constexpr bool kStoresAux = true;  // divergence row t is stored in step t
+  static constexpr bool kSteady = false;
 
   template <bool XEDGE, bool YCHK>
   static __device__ __forceinline__ R apply(const R &a, const R &b, const R &n, const A &d, int r,
@@ -534,7 +540,7 @@ template <class Op, int K, bool XEDGE> struct Pipe {
     // the general loop's code, run twice (up to RING-1 surplus steps at the end: loads are
     // clamped, stores dumped)
     int t = t0;
-    int gend = TB_STEADY && tea >= tsa ? min(tsa, t1) : t1;
+    int gend = TB_STEADY && Op::kSteady && tea >= tsa ? min(tsa, t1) : t1;
 #pragma nounroll
     for (int pass = 0; pass < 2; ++pass) {
       for (; t < gend; t += RING) {
@@ -547,7 +553,7 @@ template <class Op, int K, bool XEDGE> struct Pipe {
           step<5>(p, t + 5);
         }
       }
-      if (pass == 0 && gend < t1) {
+      if (TB_STEADY && Op::kSteady && pass == 0 && gend < t1) {
         for (; t <= tea; t += RING) {
           steady_step<0>(p, t, st);
           steady_step<1>(p, t + 1, st);
@@ -601,8 +607,9 @@ __device__ __forceinline__ void tb_kernel_body(Geom g, int r0, int r1, int chunk
 }
 
 template <int K, int C>
-// (Holding the 13-sweep form to 128 VGPRs for a fourth wave per SIMD was tried: 7 spilled
-// registers, 0.967 -> 1.133 ms per launch at 16384^2.  Left to the register allocator.)
+// (Holding the 13-sweep form to 128 VGPRs for a fourth wave per SIMD was tried twice, with
+// __launch_bounds__(256, 4) and amdgpu_waves_per_eu: 7-8 spilled registers, 0.967 -> 1.133 ms
+// per launch at 16384^2.  Left to the register allocator: 132 VGPRs.)
 __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK) void k_jacobi_tb(
     Geom g, int r0, int r1, int chunk, const float *__restrict__ pin,
     const float *__restrict__ div, float *__restrict__ pout, float *__restrict__ dump) {
