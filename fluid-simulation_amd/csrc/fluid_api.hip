@@ -453,13 +453,15 @@ int fluid_init(fluid_ctx **out, const fluid_params *p) {
   // Plan by owned cells, from sweeps on MI355X (tools/tb_sweep.py, tools/small_sweep.py):
   //   <= ~1024^2 : launch/latency bound -> short pipelines, as many waves as possible
   //   ~2048^2    : 8 sweeps per launch
-  //   ~4096^2    : fields sit in the Infinity Cache -> 10 Jacobi / 5 diffusion sweeps per launch
+  //   ~4096^2 and the slabs of a 16384^2 domain on 8 GPUs: 10 sweeps per launch, and just under
+  //                one resident round of waves (4 per SIMD x 1024 SIMDs): a few blocks over the
+  //                round cost a second one (0.718 -> 0.696 ms at 4096^2)
   //   >= 8192^2  : HBM round trips dominate -> 13-14 Jacobi / 10 diffusion sweeps per launch,
   //                twice the waves (shorter chunks even out the tail of the launch)
   const long long owned = (long long)prm.n * si.rows;
   if (owned < (1ll << 21)) { c->tb_kj = 4; c->tb_minchunk = 1; }
   else if (owned < (1ll << 23)) { c->tb_kj = 8; c->tb_minchunk = 1; }
-  else if (owned < (1ll << 26)) { c->tb_waves = 4096; }
+  else if (owned < (1ll << 26)) { c->tb_kd = 10; c->tb_waves = 3900; c->tb_minchunk = 1; }
   else { c->tb_kd = 10; c->tb_kj = 14; c->tb_waves = 16384; c->tb_minchunk = 1; }
   c->tb_kj = env_int("FLUID_TB_KJ", c->tb_kj);
   c->tb_kd = env_int("FLUID_TB_KD", c->tb_kd);

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Time one slab of an N x N domain cut into G row slabs, on one GPU, without the exchange
+(halos go stale, which does not change the work): the per-GPU compute time of the multi-GPU run.
+Usage: python tools/slab_time.py N J G [rank]"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import fluid_amd_loader  # noqa: E402
+
+pkg = fluid_amd_loader.load()
+n, J, G = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+rank = int(sys.argv[4]) if len(sys.argv) > 4 else G // 2
+sim = pkg.FluidSim(n, pressure_iters=J, slab_rank=rank, slab_count=G)
+ss = pkg.SplatStream()
+for _ in range(3):
+    sim.add_source(*ss.splat())
+for _ in range(3):
+    sim.step(1)
+sim.sync()
+for mode in ("whole", "parts"):
+    steps = 20
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        if mode == "whole":
+            sim.step(1)
+        else:
+            sim.step_part(pkg.PART_VELOCITY)
+            sim.step_part(pkg.PART_DENSITY)
+    try:
+        sim.sync()
+    except Exception as e:  # stale halos may trip the halo flag; timing is still valid
+        print("sync:", e)
+    dt = (time.perf_counter() - t0) / steps * 1e3
+    print(json.dumps({"n": n, "J": J, "slabs": G, "rank": rank, "rows": sim.rows, "mode": mode,
+                      "ms_per_step": round(dt, 4), "GCUPS_whole_job_if_all_like_this": round(n * n / dt / 1e6, 2)}), flush=True)
+try:
+    st = sim.profile_steps(1)
+    print({s["name"]: round(s["total_ms"] / max(s["launches"], 1), 4) for s in st})
+except Exception as e:
+    print("profile:", e)
