@@ -87,7 +87,8 @@ __global__ __launch_bounds__(WPB * 64) void k_burst(int n, int pitch, int chunk,
   float2 pa[B], pb[B];
   auto ld = [&](const float *f, int t) {
     typedef float f2v __attribute__((ext_vector_type(2)));
-    const f2v *q = (const f2v *)(f + (size_t)min(t, n - 1) * pitch + xc);
+    const f2v *q = pitch > 0 ? (const f2v *)(f + (size_t)min(t, n - 1) * pitch + xc)
+                             : (const f2v *)(f + ((size_t)strip * n + min(t, n - 1)) * 128 + lane * 2);
     const f2v r = NT ? __builtin_nontemporal_load(q) : *q;
     return make_float2(r.x, r.y);
   };
@@ -103,7 +104,8 @@ __global__ __launch_bounds__(WPB * 64) void k_burst(int n, int pitch, int chunk,
     for (int j = 0; j < B; ++j)
       if (t + j < yb) {
         typedef float f2v __attribute__((ext_vector_type(2)));
-        f2v *q = (f2v *)(out + (size_t)(t + j) * pitch + xc);
+        f2v *q = pitch > 0 ? (f2v *)(out + (size_t)(t + j) * pitch + xc)
+                           : (f2v *)(out + ((size_t)strip * n + t + j) * 128 + lane * 2);
         const f2v w = {v[j].x, v[j].y};
         if (NT) __builtin_nontemporal_store(w, q); else *q = w;
       }
@@ -123,6 +125,54 @@ void run_burst(const char *name, int n, int pitch, int waves, float *a, float *b
   float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); ms /= 5;
   printf("%-12s pitch=n+%-4d burst=%d wpb=%2d nt=%d xcd=%d waves=%6d chunk=%4d : %.3f ms  %.0f GB/s\n", name, pitch - n, B, WPB, (int)NT, (int)XCD,
          strips * (int)grid.y, chunk, ms, (double)n * n * 12 / ms / 1e6);
+}
+
+// MODE 0: loads only (sum kept in registers, one store at the end); 1: stores only; 2: copy with
+// stores issued in bursts of B rows after the next burst of loads.
+template <int B, int MODE>
+__global__ __launch_bounds__(256) void k_dir(int n, int chunk, const float *__restrict__ a,
+                                             const float *__restrict__ b, float *__restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int strip = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int xc = strip * 128 + lane * 2;
+  if (xc >= n) return;
+  const int ya = blockIdx.y * chunk, yb = min(ya + chunk, n);
+  float2 pa[B], pb[B], acc = make_float2(0.f, 0.f);
+  auto ld = [&](const float *f, int t) { return *(const float2 *)(f + (size_t)min(t, n - 1) * n + xc); };
+  if (MODE != 1) {
+#pragma unroll
+    for (int i = 0; i < B; ++i) { pa[i] = ld(a, ya + i); pb[i] = ld(b, ya + i); }
+  }
+  for (int t = ya; t < yb; t += B) {
+    float2 v[B];
+#pragma unroll
+    for (int j = 0; j < B; ++j) v[j] = MODE == 1 ? make_float2((float)t, (float)j) : add(pa[j], pb[j]);
+    if (MODE != 1) {
+#pragma unroll
+      for (int j = 0; j < B; ++j) { pa[j] = ld(a, t + B + j); pb[j] = ld(b, t + B + j); }
+    }
+#pragma unroll
+    for (int j = 0; j < B; ++j) {
+      if (MODE == 0) acc = add(acc, v[j]);
+      else if (t + j < yb) *(float2 *)(out + (size_t)(t + j) * n + xc) = v[j];
+    }
+  }
+  if (MODE == 0) *(float2 *)(out + (size_t)ya * n + xc) = acc;
+}
+template <int B, int MODE>
+void run_dir(const char *name, int n, int waves, float *a, float *b, float *out) {
+  const int strips = n / 128;
+  int chunks = waves / strips; if (chunks < 1) chunks = 1;
+  const int chunk = (n + chunks - 1) / chunks;
+  dim3 grid((strips + 3) / 4, (n + chunk - 1) / chunk);
+  hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  for (int i = 0; i < 2; ++i) k_dir<B, MODE><<<grid, 256>>>(n, chunk, a, b, out);
+  CHECK(hipEventRecord(e0));
+  for (int i = 0; i < 5; ++i) k_dir<B, MODE><<<grid, 256>>>(n, chunk, a, b, out);
+  CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+  float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); ms /= 5;
+  const double bytes = (double)n * n * 4 * (MODE == 0 ? 2 : MODE == 1 ? 1 : 3);
+  printf("%-12s B=%d waves=%6d chunk=%4d : %.3f ms  %.0f GB/s\n", name, B, strips * (int)grid.y, chunk, ms, bytes / ms / 1e6);
 }
 
 __global__ void k_rowmajor(size_t n4, const float4 *__restrict__ a, const float4 *__restrict__ b, float4 *__restrict__ out, int nin) {
@@ -174,11 +224,15 @@ int main(int argc, char **argv) {
       printf("row-major copy nin=%d : %.3f ms  %.0f GB/s\n", nin, ms, (double)cells * 4 * (nin + 1) / ms / 1e6);
     }
   }
-  for (int waves : {8192, 16384}) {
-    for (int pad : {0, 32, 64, 128, 256, 512, 1024, 2048, 4096 + 64})  {
-      run_burst<1, 4, false, false>("burst", n, n + pad, waves, a, b, out);
-      run_burst<4, 4, false, false>("burst", n, n + pad, waves, a, b, out);
-    }
+  for (int waves : {4096, 8192, 16384}) {
+    run_dir<1, 0>("loads-only", n, waves, a, b, out);
+    run_dir<3, 0>("loads-only", n, waves, a, b, out);
+    run_dir<8, 0>("loads-only", n, waves, a, b, out);
+    run_dir<1, 1>("stores-only", n, waves, a, b, out);
+    run_dir<3, 1>("stores-only", n, waves, a, b, out);
+    run_dir<1, 2>("copy", n, waves, a, b, out);
+    run_dir<3, 2>("copy-burst", n, waves, a, b, out);
+    run_dir<8, 2>("copy-burst", n, waves, a, b, out);
   }
   if (argc > 2)
   for (int waves : {8192, 16384, 32768}) {
