@@ -70,7 +70,7 @@ def cpu_baseline(pkg, D, J, budget_s=12.0):
         sim.step(1)
         steps += 1
         el = time.perf_counter() - t0
-        if el >= budget_s or steps >= 50:
+        if el >= budget_s or steps >= 400:
             break
     return {
         "value": round(n * n * steps / el / 1e9, 6), "unit": "GCUPS", "cores": 1, "kind": "port",
