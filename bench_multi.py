@@ -28,6 +28,18 @@ def run_multi(pkg, args, n, D, J, flags):
     else:
         dist.init_process_group(backend, rank=rank, world_size=world)
 
+    # Deep pressure loops on short slabs: the J sweeps can be cut into groups with a pressure-halo
+    # exchange in between (include/fluid.h, pressure_groups).  Measured on one MI355X (tools/
+    # slab_time.py, 8192^2, J = 200, one of 8 slabs, no exchange): 1.38 ms with one group (219 halo
+    # rows), 1.31 ms with 3-5 groups — less than the three extra exposed exchanges would cost, so
+    # groups are used only when a slab is too short for the one-exchange halo.
+    rows_min = n // world
+    groups = 1
+    while groups < J and (J + groups - 1) // groups + 1 + D + 8 > rows_min:
+        groups += 1
+    groups = int(os.environ.get("FLUID_BENCH_GROUPS", groups))
+    gkw = {"pressure_groups": groups} if groups > 1 else {}
+
     # Self-check on the real transport before timing: the overlapped exchange must give the bits
     # of the plain one (3 steps from the same splats); otherwise time the plain path.
     import numpy as np
@@ -36,7 +48,7 @@ def run_multi(pkg, args, n, D, J, flags):
         sums = []
         for ov in (True, False):
             s_ = SlabSim(pkg, n, rank=rank, world=world, device_index=local, diffusion_iters=D,
-                         pressure_iters=J, flags=flags, overlap=ov)
+                         pressure_iters=J, flags=flags, overlap=ov, **gkw)
             seeded_warm_state(pkg, s_)
             s_.step(3)
             s_.sync()
@@ -47,7 +59,7 @@ def run_multi(pkg, args, n, D, J, flags):
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         overlap_ok = bool(ok.item())
     sim = SlabSim(pkg, n, rank=rank, world=world, device_index=local, diffusion_iters=D,
-                  pressure_iters=J, flags=flags, overlap=None if overlap_ok else False)
+                  pressure_iters=J, flags=flags, overlap=None if overlap_ok else False, **gkw)
     seeded_warm_state(pkg, sim)          # every rank applies the same splats to its own rows
     sim.step(args.warmup)
     sim.sync()
@@ -66,7 +78,7 @@ def run_multi(pkg, args, n, D, J, flags):
     if rank == 0:
         t_step = wall / args.steps
         bpc = pkg.alg_bytes_per_cell(D, J)
-        plan = pkg.FluidLib().slab_plan(n, 0, world, diffusion_iters=D, pressure_iters=J)
+        plan = pkg.FluidLib().slab_plan(n, 0, world, diffusion_iters=D, pressure_iters=J, pressure_groups=groups)
         out = {
             "metric": "cell-updates/sec per full timestep (GCUPS)",
             "value": round(n * n / t_step / 1e9, 4), "unit": "GCUPS", "n_gpus": world,
@@ -77,7 +89,10 @@ def run_multi(pkg, args, n, D, J, flags):
                        "name": args.workload, "path": "unfused" if args.unfused else "fused",
                        "decomposition": f"{world} row slabs of {plan['rows']} rows, one halo exchange per "
                                         f"step ({plan['halo_vel']} velocity + {plan['halo_dens']} density rows "
-                                        f"per neighbour) over {'RCCL send/recv' if backend == 'nccl' else backend}"},
+                                        f"per neighbour"
+                                        + (f", pressure sweeps in {plan['pressure_groups']} groups with {plan['halo_prs']} "
+                                           f"pressure rows exchanged between groups" if plan['pressure_groups'] > 1 else "")
+                                        + f") over {'RCCL send/recv' if backend == 'nccl' else backend}"},
             "step_alg_bytes_per_cell": bpc,
             "step_effective_GBps": round(bpc * n * n / t_step / 1e9, 1),
             "step_frac_of_hbm_peak": round(bpc * n * n / t_step / 1e9 / (HBM_PEAK_GBPS * world), 4),

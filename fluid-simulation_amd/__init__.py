@@ -10,7 +10,8 @@ library or without a GPU raises.  Nothing in this package imports ``oracle/``.
 """
 from .capi import (FluidLib, FluidSim, FluidError, FluidParams, KernelStat, SlabInfo, hip_lib_path,
                    FIELD_VELOCITY, FIELD_DENSITY, FIELD_PRESSURE, FIELD_DIVERGENCE,
-                   FIELD_VORTICITY, FLAG_VORTICITY, FLAG_NO_GRAPH, FLAG_UNFUSED, ABI_SYMBOLS, PART_VELOCITY, PART_DENSITY)
+                   FIELD_VORTICITY, FLAG_VORTICITY, FLAG_NO_GRAPH, FLAG_UNFUSED, ABI_SYMBOLS, PART_VELOCITY, PART_DENSITY,
+                   PART_VELOCITY_HEAD, PART_PRESSURE_GROUP, PART_VELOCITY_TAIL)
 from . import viz, replay as replay_mod
 from .replay import replay, parse_events
 from .splats import SplatStream, COLOR_PRESETS, alg_bytes_per_cell, run_seeded, DEFAULT_SEED
@@ -19,5 +20,6 @@ __all__ = [
     "FluidLib", "FluidSim", "FluidError", "FluidParams", "KernelStat", "hip_lib_path",
     "FIELD_VELOCITY", "FIELD_DENSITY", "FIELD_PRESSURE", "FIELD_DIVERGENCE", "FIELD_VORTICITY",
     "FLAG_VORTICITY", "FLAG_NO_GRAPH", "FLAG_UNFUSED", "ABI_SYMBOLS", "PART_VELOCITY", "PART_DENSITY",
+    "PART_VELOCITY_HEAD", "PART_PRESSURE_GROUP", "PART_VELOCITY_TAIL",
     "viz", "replay", "parse_events", "SplatStream", "COLOR_PRESETS", "alg_bytes_per_cell", "run_seeded", "DEFAULT_SEED",
 ]

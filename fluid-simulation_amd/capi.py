@@ -29,6 +29,7 @@ ABI_SYMBOLS = [
     "fluid_step_part", "fluid_halo_bytes_part", "fluid_halo_pack_part", "fluid_halo_unpack_part",
 ]
 PART_VELOCITY, PART_DENSITY = 1, 2
+PART_VELOCITY_HEAD, PART_PRESSURE_GROUP, PART_VELOCITY_TAIL = 4, 8, 16
 
 
 class FluidParams(C.Structure):
@@ -36,13 +37,13 @@ class FluidParams(C.Structure):
         ("n", C.c_int), ("diffusion_iters", C.c_int), ("pressure_iters", C.c_int),
         ("dt", C.c_float), ("viscosity", C.c_float), ("splat_radius", C.c_float),
         ("device", C.c_int), ("flags", C.c_uint), ("slab_rank", C.c_int), ("slab_count", C.c_int),
-        ("halo_rows", C.c_int), ("reserved", C.c_int * 5),
+        ("halo_rows", C.c_int), ("pressure_groups", C.c_int), ("reserved", C.c_int * 4),
     ]
 
 
 class SlabInfo(C.Structure):
     _fields_ = [(k, C.c_int) for k in ("n", "row0", "rows", "halo_vel", "halo_dens", "store_row0",
-                                       "store_rows", "has_lo", "has_hi")]
+                                       "store_rows", "has_lo", "has_hi", "pressure_groups", "halo_prs")]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -126,10 +127,11 @@ class FluidLib:
         sig("fluid_halo_unpack_part", C.c_int, P, C.c_int, C.c_int, P, P, required=False)
 
     def slab_plan(self, n, slab_rank, slab_count, *, diffusion_iters=None, pressure_iters=None,
-                  halo_rows=0) -> dict:
+                  halo_rows=0, pressure_groups=0) -> dict:
         """fluid_slab_plan: pure host arithmetic, needs no GPU."""
         p = self.default_params()
         p.n, p.slab_rank, p.slab_count, p.halo_rows = n, slab_rank, slab_count, halo_rows
+        p.pressure_groups = pressure_groups
         if diffusion_iters is not None:
             p.diffusion_iters = diffusion_iters
         if pressure_iters is not None:
@@ -176,7 +178,7 @@ class FluidSim:
                  pressure_iters: Optional[int] = None, dt: Optional[float] = None,
                  viscosity: Optional[float] = None, splat_radius: Optional[float] = None,
                  device: int = 0, flags: int = 0, slab_rank: int = 0, slab_count: int = 0,
-                 halo_rows: int = 0, lib: Optional[FluidLib] = None):
+                 halo_rows: int = 0, pressure_groups: int = 0, lib: Optional[FluidLib] = None):
         self.lib = lib or _get_default_lib()
         p = self.lib.default_params()
         if n is not None:
@@ -193,6 +195,7 @@ class FluidSim:
             p.splat_radius = splat_radius
         p.device, p.flags = device, flags
         p.slab_rank, p.slab_count, p.halo_rows = slab_rank, slab_count, halo_rows
+        p.pressure_groups = pressure_groups
         self.params = p
         self._h = C.c_void_p()
         rc = self.lib.dll.fluid_init(C.byref(self._h), C.byref(p))
@@ -203,6 +206,11 @@ class FluidSim:
         self._chk(self.lib.dll.fluid_geometry(self._h, C.byref(n_), C.byref(r0), C.byref(rows)),
                   "fluid_geometry")
         self.n, self.row0, self.rows = n_.value, r0.value, rows.value
+        self.pressure_groups = 1
+        if slab_count > 1 and pressure_groups > 1:
+            self.pressure_groups = self.lib.slab_plan(
+                self.n, slab_rank, slab_count, diffusion_iters=p.diffusion_iters, pressure_iters=p.pressure_iters,
+                halo_rows=halo_rows, pressure_groups=pressure_groups)["pressure_groups"]
 
     # -- plumbing ---------------------------------------------------------------
     def _chk(self, rc: int, what: str):

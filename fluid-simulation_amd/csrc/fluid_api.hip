@@ -38,6 +38,8 @@ struct fluid_ctx {
   int row0 = 0, rows = 0;  // owned global rows [row0, row0 + rows)
   int own_r0 = 0;          // local row of the first owned row
   int halo_vel = 0, halo_dens = 0, adv_rows = 0;  // slab halos (fluid_slab_plan); 0 when whole-domain
+  int groups = 1, jg = 0, halo_prs = 0;  // pressure groups: count, sweeps per group, rows exchanged
+  int pgroup = 0;                        // next pressure group to run in the current step
   bool slab = false, has_lo = false, has_hi = false;
   float2 *vel[2] = {nullptr, nullptr};   // velocityBufferArray[2]  kernel.cu:443-444
   float4 *dens[2] = {nullptr, nullptr};  // densityBufferArray[2]   kernel.cu:447-448
@@ -226,31 +228,40 @@ void enq_vorticity(fluid_ctx *c) {
   }
 }
 
-// projection()  kernel.cu:604-662.  The projected velocity is produced on the owned rows;
-// it needs p^J one row beyond, hence p^j on 1 + J - j rows beyond and the divergence on J.
-void enq_project(fluid_ctx *c, bool with_density = false) {
+// projection()  kernel.cu:604-662, first half: divergence, pressure clear and the Jacobi sweeps,
+// in `groups` groups (one unless the context was made with pressure_groups; then the caller
+// exchanges halo_prs pressure rows between groups).  The projected velocity is produced on the
+// owned rows; it needs p^J one row beyond, hence within a group p on 1 + left rows beyond when
+// `left` sweeps of the group are still to come, and the divergence on (group length) rows.
+void enq_pressure_group(fluid_ctx *c, int g) {
   const double cells = (double)cells_owned(c);
   const int J = c->prm.pressure_iters;
+  const int glen = c->groups > 1 ? c->jg : J;
+  const int first = g * glen, last = first + glen < J ? first + glen : J;
+  int left = last - first;  // sweeps of this group
   const bool tb = use_tb(c, c->tb_cj);
-  int left = J;
-  if (tb && J > 0) {
-    // divergence + resetPressure (p^0 == 0 is a constant, not a buffer) + the first sweeps
-    const int k = next_pass(left, c->tb_kj, c->tb_cj, false);
-    ProfScope p(c, K_JACOBI_DIV_TB, 12.0 * cells + 12.0 * k * cells);
-    const Range r = widened(c, 1 + left - k);
-    launch_jacobi_div_tb(c->stream, c->g, r.r0, r.r1, k, c->tb_cj, tb_chunk(c, k, c->tb_cj, r.r1 - r.r0),
-                         c->vel[c->vin], c->div, c->prs[c->pin ^ 1], c->dump);
-    c->pin ^= 1;
-    left -= k;
-  } else {
-    {
-      ProfScope p(c, K_DIVERGENCE, 12.0 * cells);
-      const Range r = widened(c, J);
-      launch_divergence(c->stream, c->g, r.r0, r.r1, c->vel[c->vin], c->div);
+  if (g == 0) {
+    // the divergence must cover what every later group's first sweep reads: glen rows beyond
+    const int div_m = c->groups > 1 ? glen : -1;
+    if (tb && left > 0) {
+      // divergence + resetPressure (p^0 == 0 is a constant, not a buffer) + the first sweeps
+      const int k = next_pass(left, c->tb_kj, c->tb_cj, false);
+      ProfScope p(c, K_JACOBI_DIV_TB, 12.0 * cells + 12.0 * k * cells);
+      const Range r = widened(c, div_m >= 0 ? div_m : 1 + left - k);
+      launch_jacobi_div_tb(c->stream, c->g, r.r0, r.r1, k, c->tb_cj, tb_chunk(c, k, c->tb_cj, r.r1 - r.r0),
+                           c->vel[c->vin], c->div, c->prs[c->pin ^ 1], c->dump);
+      c->pin ^= 1;
+      left -= k;
+    } else {
+      {
+        ProfScope p(c, K_DIVERGENCE, 12.0 * cells);
+        const Range r = widened(c, div_m >= 0 ? div_m : J);
+        launch_divergence(c->stream, c->g, r.r0, r.r1, c->vel[c->vin], c->div);
+      }
+      // resetPressure()  kernel.cu:530-540: only the pressure clear is live (the
+      // other two targets are overwritten before they are read).
+      (void)hipMemsetAsync(c->prs[c->pin], 0, cells_local(c) * sizeof(float), c->stream);
     }
-    // resetPressure()  kernel.cu:530-540: only the pressure clear is live (the
-    // other two targets are overwritten before they are read).
-    (void)hipMemsetAsync(c->prs[c->pin], 0, cells_local(c) * sizeof(float), c->stream);
   }
   if (tb) {
     while (left > 0) {
@@ -263,13 +274,18 @@ void enq_project(fluid_ctx *c, bool with_density = false) {
       left -= k;
     }
   } else {
-    for (int i = 0; i < J; ++i) {
+    for (; left > 0; --left) {
       ProfScope p(c, K_JACOBI, 12.0 * cells);
-      const Range r = widened(c, J - i);
+      const Range r = widened(c, left);
       launch_jacobi(c->stream, c->g, r.r0, r.r1, c->prs[c->pin], c->div, c->prs[c->pin ^ 1]);
       c->pin ^= 1;
     }
   }
+}
+
+// projection(), second half: the gradient subtraction, kernel.cu:655-661.
+void enq_gradient(fluid_ctx *c, bool with_density) {
+  const double cells = (double)cells_owned(c);
   if (with_density) {
     // + simulateDensityAdvection() kernel.cu:664-685 on the same rows (see enq_step)
     ProfScope p(c, K_PROJECT_ADVECT_DENS, 60.0 * cells);
@@ -282,12 +298,15 @@ void enq_project(fluid_ctx *c, bool with_density = false) {
     c->din ^= 1;
     return;
   }
-  {
-    ProfScope p(c, K_PROJECT, 20.0 * cells);
-    const Range r = widened(c, 0);
-    launch_project(c->stream, c->g, r.r0, r.r1, c->vel[c->vin], c->prs[c->pin], c->vel[c->vin ^ 1]);
-    c->vin ^= 1;
-  }
+  ProfScope p(c, K_PROJECT, 20.0 * cells);
+  const Range r = widened(c, 0);
+  launch_project(c->stream, c->g, r.r0, r.r1, c->vel[c->vin], c->prs[c->pin], c->vel[c->vin ^ 1]);
+  c->vin ^= 1;
+}
+
+void enq_project(fluid_ctx *c, bool with_density = false) {  // one group: the whole projection()
+  enq_pressure_group(c, 0);
+  enq_gradient(c, with_density);
 }
 
 // simulateDensityAdvection()  kernel.cu:664-685
@@ -302,19 +321,27 @@ void enq_advect_density(fluid_ctx *c) {
 }
 
 // simulationStep()  kernel.cu:701-708
+void enq_velocity_head(fluid_ctx *c) {
+  // margins of the dependency cone (zero-width for whole-domain contexts, see widened())
+  const int glen = c->groups > 1 ? c->jg : c->prm.pressure_iters;
+  const int m_diff = glen + 1;  // diffused velocity feeds divergence on glen rows
+  enq_advect_velocity(c, m_diff + c->prm.diffusion_iters);
+  enq_diffuse(c, m_diff);
+  if (c->prm.flags & FLUID_FLAG_VORTICITY) enq_vorticity(c);  // kernel.cu:705
+  enq_pressure_group(c, 0);
+}
 void enq_step(fluid_ctx *c, int parts) {
-  if (parts & FLUID_PART_VELOCITY) {
-    // margins of the dependency cone (zero-width for whole-domain contexts, see widened())
-    const int m_diff = c->prm.pressure_iters + 1;  // diffused velocity feeds divergence on J rows
-    enq_advect_velocity(c, m_diff + c->prm.diffusion_iters);
-    enq_diffuse(c, m_diff);
-    if (c->prm.flags & FLUID_FLAG_VORTICITY) enq_vorticity(c);  // kernel.cu:705
+  if (parts & FLUID_PART_VELOCITY) {  // one pressure group (checked by the callers)
+    enq_velocity_head(c);
     // When the whole step is enqueued at once, the gradient subtraction and the density
     // advection (both over the owned rows) run as one kernel.
     const bool fuse = (parts & FLUID_PART_DENSITY) && !(c->prm.flags & FLUID_FLAG_UNFUSED);
-    enq_project(c, fuse);
+    enq_gradient(c, fuse);
     if (fuse) return;
   }
+  if (parts & FLUID_PART_VELOCITY_HEAD) enq_velocity_head(c);
+  if (parts & FLUID_PART_PRESSURE_GROUP) enq_pressure_group(c, c->pgroup);
+  if (parts & FLUID_PART_VELOCITY_TAIL) enq_gradient(c, false);
   if (parts & FLUID_PART_DENSITY) enq_advect_density(c);
 }
 
@@ -333,7 +360,7 @@ int run_steps(fluid_ctx *c, int nsteps, int parts = FLUID_PART_VELOCITY | FLUID_
       if (rc) return rc;
       continue;
     }
-    const int key = state_of(c) | (parts << 3);
+    const int key = state_of(c) | (parts << 3) | (c->pgroup << 8);
     auto it = c->graphs.find(key);
     if (it == c->graphs.end()) {
       GraphEntry ge;
@@ -404,6 +431,7 @@ int fluid_slab_plan(const fluid_params *p, fluid_slab_info *out) {
   if (p->slab_count <= 1) {
     out->rows = p->n;
     out->store_rows = p->n;
+    out->pressure_groups = 1;
     return FLUID_OK;
   }
   if (p->slab_rank < 0 || p->slab_rank >= p->slab_count) return FLUID_E_INVALID;
@@ -412,7 +440,12 @@ int fluid_slab_plan(const fluid_params *p, fluid_slab_info *out) {
   const int row1 = (int)((long long)p->n * (p->slab_rank + 1) / p->slab_count);
   out->rows = row1 - out->row0;
   out->halo_dens = a;
-  out->halo_vel = p->pressure_iters + 1 + p->diffusion_iters + a;
+  out->pressure_groups = p->pressure_groups > 1 && p->pressure_iters > 1
+                             ? (p->pressure_groups < p->pressure_iters ? p->pressure_groups : p->pressure_iters) : 1;
+  const int jg = (p->pressure_iters + out->pressure_groups - 1) / out->pressure_groups;
+  out->pressure_groups = jg > 0 ? (p->pressure_iters + jg - 1) / jg : 1;  // no empty last group
+  out->halo_prs = out->pressure_groups > 1 ? jg + 1 : 0;
+  out->halo_vel = jg + 1 + p->diffusion_iters + a;
   out->has_lo = p->slab_rank > 0;
   out->has_hi = p->slab_rank < p->slab_count - 1;
   // a halo must come from the adjacent slab alone, and the y-border rules read two rows inward
@@ -447,6 +480,9 @@ int fluid_init(fluid_ctx **out, const fluid_params *p) {
   c->slab = prm.slab_count > 1;
   c->halo_vel = si.halo_vel;
   c->halo_dens = si.halo_dens;
+  c->groups = si.pressure_groups;
+  c->halo_prs = si.halo_prs;
+  c->jg = c->groups > 1 ? si.halo_prs - 1 : prm.pressure_iters;
   c->has_lo = si.has_lo;
   c->has_hi = si.has_hi;
   // tuning knobs (defaults chosen from measurements); results do not depend on them
@@ -460,7 +496,7 @@ int fluid_init(fluid_ctx **out, const fluid_params *p) {
   //                twice the waves (shorter chunks even out the tail of the launch)
   const long long owned = (long long)prm.n * si.rows;
   if (owned < (1ll << 21)) { c->tb_kj = 4; c->tb_minchunk = 1; }
-  else if (owned < (1ll << 23)) { c->tb_kj = 8; c->tb_minchunk = 1; }
+  else if (owned <= (1ll << 23)) { c->tb_kj = 8; c->tb_minchunk = 1; }
   else if (owned < (1ll << 26)) { c->tb_kd = 10; c->tb_waves = 3900; c->tb_minchunk = 1; }
   else { c->tb_kd = 10; c->tb_kj = 14; c->tb_waves = 16384; c->tb_minchunk = 1; }
   c->tb_kj = env_int("FLUID_TB_KJ", c->tb_kj);
@@ -548,6 +584,7 @@ int fluid_add_source(fluid_ctx *c, float sx, float sy, float fx, float fy, const
 int fluid_step(fluid_ctx *c, int nsteps) {
   if (!c || nsteps < 0) return FLUID_E_INVALID;
   if (c->slab && nsteps > 1) return FLUID_E_UNSUPPORTED;  // halos must be refreshed before every step
+  if (c->groups > 1 && nsteps > 0) return FLUID_E_UNSUPPORTED;  // pressure halos between groups: fluid_step_part
   HIPCHK(c, hipSetDevice(c->prm.device));
   return run_steps(c, nsteps);
 }
@@ -692,9 +729,43 @@ int fluid_profile_steps(fluid_ctx *c, int nsteps, fluid_kernel_stat *stats, int 
 }
 
 int fluid_step_part(fluid_ctx *c, int part) {
-  if (!c || (part != FLUID_PART_VELOCITY && part != FLUID_PART_DENSITY)) return FLUID_E_INVALID;
+  if (!c) return FLUID_E_INVALID;
+  switch (part) {
+    case FLUID_PART_VELOCITY:
+      if (c->groups > 1) return FLUID_E_UNSUPPORTED;
+      break;
+    case FLUID_PART_DENSITY:
+      break;
+    case FLUID_PART_VELOCITY_HEAD:
+      c->pgroup = 0;
+      break;
+    case FLUID_PART_PRESSURE_GROUP:  // groups 1 .. groups-1, in order, after the head
+      if (c->pgroup < 1 || c->pgroup >= c->groups) return fail(c, FLUID_E_INVALID, "no pressure group pending");
+      break;
+    case FLUID_PART_VELOCITY_TAIL:
+      if (c->pgroup != c->groups) return fail(c, FLUID_E_INVALID, "pressure groups not finished");
+      break;
+    default:
+      return FLUID_E_INVALID;
+  }
   HIPCHK(c, hipSetDevice(c->prm.device));
-  return run_steps(c, 1, part);
+  const int rc = run_steps(c, 1, part);
+  if (rc) return rc;
+  if (part == FLUID_PART_VELOCITY_HEAD) c->pgroup = 1;
+  else if (part == FLUID_PART_PRESSURE_GROUP) ++c->pgroup;
+  else if (part == FLUID_PART_VELOCITY_TAIL) c->pgroup = 0;
+  return FLUID_OK;
+}
+
+// One field's halo block: which buffer, how many rows, bytes per cell.
+struct HaloField { char *base; int rows; size_t esize; };
+static bool halo_field(const fluid_ctx *c, int part, HaloField *f) {
+  switch (part) {
+    case FLUID_PART_VELOCITY: *f = HaloField{(char *)c->vel[c->vin], c->halo_vel, sizeof(float2)}; return true;
+    case FLUID_PART_DENSITY: *f = HaloField{(char *)c->dens[c->din], c->halo_dens, sizeof(float4)}; return true;
+    case FLUID_PART_PRESSURE_GROUP: *f = HaloField{(char *)c->prs[c->pin], c->halo_prs, sizeof(float)}; return c->halo_prs > 0;
+    default: return false;
+  }
 }
 
 size_t fluid_halo_bytes_part(const fluid_ctx *c, int dir, int parts) {
@@ -703,6 +774,7 @@ size_t fluid_halo_bytes_part(const fluid_ctx *c, int dir, int parts) {
   size_t b = 0;
   if (parts & FLUID_PART_VELOCITY) b += (size_t)c->g.n * c->halo_vel * sizeof(float2);
   if (parts & FLUID_PART_DENSITY) b += (size_t)c->g.n * c->halo_dens * sizeof(float4);
+  if (parts & FLUID_PART_PRESSURE_GROUP) b += (size_t)c->g.n * c->halo_prs * sizeof(float);
   return b;
 }
 
@@ -712,38 +784,26 @@ size_t fluid_halo_bytes(const fluid_ctx *c, int dir) {
 
 // One field's halo block; stream NULL = the context's stream.
 int fluid_halo_pack_part(fluid_ctx *c, int dir, int part, void *dst, void *stream) {
-  if (!c || !dst || (part != FLUID_PART_VELOCITY && part != FLUID_PART_DENSITY)) return FLUID_E_INVALID;
+  HaloField f;
+  if (!c || !dst || !halo_field(c, part, &f)) return FLUID_E_INVALID;
   if (!fluid_halo_bytes_part(c, dir, part)) return FLUID_E_INVALID;
   HIPCHK(c, hipSetDevice(c->prm.device));
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
-  const size_t n = c->g.n;
-  if (part == FLUID_PART_VELOCITY) {
-    const size_t r = dir < 0 ? c->own_r0 : c->own_r0 + c->rows - c->halo_vel;
-    HIPCHK(c, hipMemcpyAsync(dst, c->vel[c->vin] + r * n, (size_t)c->halo_vel * n * sizeof(float2),
-                             hipMemcpyDeviceToDevice, st));
-  } else {
-    const size_t r = dir < 0 ? c->own_r0 : c->own_r0 + c->rows - c->halo_dens;
-    HIPCHK(c, hipMemcpyAsync(dst, c->dens[c->din] + r * n, (size_t)c->halo_dens * n * sizeof(float4),
-                             hipMemcpyDeviceToDevice, st));
-  }
+  const size_t row = (size_t)c->g.n * f.esize;
+  const size_t r = dir < 0 ? c->own_r0 : c->own_r0 + c->rows - f.rows;  // owned rows next to that neighbour
+  HIPCHK(c, hipMemcpyAsync(dst, f.base + r * row, f.rows * row, hipMemcpyDeviceToDevice, st));
   return FLUID_OK;
 }
 
 int fluid_halo_unpack_part(fluid_ctx *c, int dir, int part, const void *src, void *stream) {
-  if (!c || !src || (part != FLUID_PART_VELOCITY && part != FLUID_PART_DENSITY)) return FLUID_E_INVALID;
+  HaloField f;
+  if (!c || !src || !halo_field(c, part, &f)) return FLUID_E_INVALID;
   if (!fluid_halo_bytes_part(c, dir, part)) return FLUID_E_INVALID;
   HIPCHK(c, hipSetDevice(c->prm.device));
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
-  const size_t n = c->g.n;
-  if (part == FLUID_PART_VELOCITY) {
-    const size_t r = dir < 0 ? c->own_r0 - c->halo_vel : c->own_r0 + c->rows;
-    HIPCHK(c, hipMemcpyAsync(c->vel[c->vin] + r * n, src, (size_t)c->halo_vel * n * sizeof(float2),
-                             hipMemcpyDeviceToDevice, st));
-  } else {
-    const size_t r = dir < 0 ? c->own_r0 - c->halo_dens : c->own_r0 + c->rows;
-    HIPCHK(c, hipMemcpyAsync(c->dens[c->din] + r * n, src, (size_t)c->halo_dens * n * sizeof(float4),
-                             hipMemcpyDeviceToDevice, st));
-  }
+  const size_t row = (size_t)c->g.n * f.esize;
+  const size_t r = dir < 0 ? c->own_r0 - f.rows : c->own_r0 + c->rows;  // halo rows just outside the owned rows
+  HIPCHK(c, hipMemcpyAsync(f.base + r * row, src, f.rows * row, hipMemcpyDeviceToDevice, st));
   return FLUID_OK;
 }
 

@@ -121,6 +121,26 @@ class SlabSim:
         self.overlap = (os.environ.get("FLUID_SLAB_OVERLAP", "1") != "0") if overlap is None else overlap
         self.ex = HaloExchanger(rank, world, torch.device("cuda", device_index), group)
         self.V, self.D = pkg.PART_VELOCITY, pkg.PART_DENSITY
+        self.P = pkg.PART_PRESSURE_GROUP
+        self.groups = self.sim.pressure_groups
+
+    def _velocity_part(self):
+        """The velocity part on the compute stream.  With pressure groups (deep Jacobi loops on
+        short slabs) the sweeps run group by group with an exchange of pressure halo rows in
+        between; those exchanges are on the critical path."""
+        sim = self.sim
+        with self.torch.cuda.stream(self.stream):
+            if self.groups <= 1:
+                sim.step_part(self.V)
+                return
+            sim.step_part(self.pkg.PART_VELOCITY_HEAD)
+        for _ in range(self.groups - 1):
+            self._start(self.P)
+            self._finish(self.P)
+            with self.torch.cuda.stream(self.stream):
+                sim.step_part(self.P)
+        with self.torch.cuda.stream(self.stream):
+            sim.step_part(self.pkg.PART_VELOCITY_TAIL)
 
     # -- exchanges -------------------------------------------------------------------------
     def _start(self, part):
@@ -139,7 +159,7 @@ class SlabSim:
                            if keep else None)
 
     def _discard_in_flight(self):
-        for part in (self.V, self.D):
+        for part in (self.V, self.D, self.P):
             if self.ex.in_flight(part):
                 self._finish(part, keep=False)
 
@@ -151,10 +171,15 @@ class SlabSim:
     def step(self, nsteps: int = 1):
         sim, V, D = self.sim, self.V, self.D
         if not self.overlap:
-            with self.torch.cuda.stream(self.stream):
-                for _ in range(nsteps):
+            for _ in range(nsteps):
+                with self.torch.cuda.stream(self.stream):
                     self.ex.exchange(sim.halo_bytes(-1), sim.halo_bytes(+1), sim.halo_pack, sim.halo_unpack)
-                    sim.step(1)
+                    if self.groups <= 1:
+                        sim.step(1)
+                        continue
+                self._velocity_part()
+                with self.torch.cuda.stream(self.stream):
+                    sim.step_part(D)
             return
         for _ in range(nsteps):
             if not self.ex.in_flight(V):
@@ -162,8 +187,7 @@ class SlabSim:
             if not self.ex.in_flight(D):
                 self._start(D)
             self._finish(V)
-            with self.torch.cuda.stream(self.stream):
-                sim.step_part(V)
+            self._velocity_part()
             self._start(V)        # next step's velocity halos: travel during the density part
             self._finish(D)
             with self.torch.cuda.stream(self.stream):
@@ -205,6 +229,22 @@ class LocalSlabGroup:
         dev = torch.device("cuda", device_index)
         mk = lambda nbytes: torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
         self.send = [{-1: mk(s.halo_bytes(-1)), +1: mk(s.halo_bytes(+1))} for s in self.sims]
+        self.groups = self.sims[0].pressure_groups
+
+    def _exchange_part(self, part):
+        for r, s in enumerate(self.sims):
+            for d in (-1, +1):
+                if s.halo_bytes_part(d, part):
+                    s.halo_pack_part(d, part, self.send[r][d].data_ptr(), None)
+        for s in self.sims:
+            s.sync()
+        for r, s in enumerate(self.sims):
+            if s.halo_bytes_part(-1, part):
+                s.halo_unpack_part(-1, part, self.send[r - 1][+1].data_ptr(), None)
+            if s.halo_bytes_part(+1, part):
+                s.halo_unpack_part(+1, part, self.send[r + 1][-1].data_ptr(), None)
+        for s in self.sims:
+            s.sync()
 
     def add_source(self, *a, **k):
         for s in self.sims:
@@ -223,8 +263,20 @@ class LocalSlabGroup:
                     s.halo_unpack(-1, self.send[r - 1][+1].data_ptr())
                 if s.halo_bytes(+1):
                     s.halo_unpack(+1, self.send[r + 1][-1].data_ptr())
-            for s in self.sims:
-                s.step(1)
+            if self.groups <= 1:
+                for s in self.sims:
+                    s.step(1)
+            else:
+                P = self.pkg.PART_PRESSURE_GROUP
+                for s in self.sims:
+                    s.step_part(self.pkg.PART_VELOCITY_HEAD)
+                for _ in range(self.groups - 1):
+                    self._exchange_part(P)
+                    for s in self.sims:
+                        s.step_part(P)
+                for s in self.sims:
+                    s.step_part(self.pkg.PART_VELOCITY_TAIL)
+                    s.step_part(self.pkg.PART_DENSITY)
             for s in self.sims:
                 s.sync()
 

@@ -88,7 +88,9 @@ typedef struct fluid_params {
   int slab_rank;       /* 0 .. slab_count-1                                   */
   int slab_count;      /* 0 or 1 = no decomposition                           */
   int halo_rows;       /* A: advection reach in rows when slab-decomposed (0 = 8) */
-  int reserved[5];     /* must be zero                                        */
+  int pressure_groups; /* slab contexts: split the J sweeps into this many groups with a
+                          pressure-halo exchange between them (0/1 = one group); see below */
+  int reserved[4];     /* must be zero                                        */
 } fluid_params;
 
 typedef struct fluid_ctx fluid_ctx;
@@ -178,7 +180,7 @@ FLUID_API int fluid_profile_steps(fluid_ctx *ctx, int nsteps, fluid_kernel_stat 
  *
  * No counterpart in the reference (single GPU).  The step's dependency cone is
  * covered by ONE exchange before the step: each slab receives
- *   halo_vel  = J + 1 + D + A   rows of velocity and
+ *   halo_vel  = J + 1 + D + A   rows of velocity (Jg instead of J with pressure groups) and
  *   halo_dens = A               rows of density
  * from each neighbour (J = pressure_iters, D = diffusion_iters, A = halo_rows,
  * the advection reach in rows, default 8) and recomputes the shrinking cone in
@@ -201,6 +203,8 @@ typedef struct fluid_slab_info {
   int halo_vel, halo_dens;      /* rows exchanged per neighbour per step            */
   int store_row0, store_rows;   /* rows kept in the local buffers (owned + halos)   */
   int has_lo, has_hi;           /* neighbour below / above exists                   */
+  int pressure_groups;          /* groups the J sweeps are split into (>= 1)        */
+  int halo_prs;                 /* pressure rows exchanged between groups (0 if one) */
 } fluid_slab_info;
 
 /* Pure host arithmetic (needs no GPU): the geometry fluid_init will use for p. */
@@ -216,8 +220,24 @@ FLUID_API size_t fluid_halo_bytes(const fluid_ctx *ctx, int dir);
  * density advection runs, and the density halos while step s+1's velocity part runs
  * (fluid-simulation_amd/slab.py).  pack/unpack_part move one field's halo block; `stream` is the
  * hipStream_t to enqueue the copy on (NULL = the context's stream).  Works on whole-domain
- * contexts too (fluid_step_part only). */
-enum { FLUID_PART_VELOCITY = 1, FLUID_PART_DENSITY = 2 };
+ * contexts too (fluid_step_part only).
+ *
+ * Deep pressure loops on short slabs (J = 200 on 1024-row slabs: 219 halo rows) can be cut into
+ * fluid_params.pressure_groups groups of Jg = ceil(J / groups) sweeps with an exchange of
+ * halo_prs = Jg + 1 pressure rows between groups; the velocity halo shrinks to Jg + 1 + D + A.
+ * The velocity part is then driven as
+ *   fluid_step_part(VELOCITY_HEAD)    advection, diffusion, divergence, sweeps of group 0
+ *   { exchange FLUID_PART_PRESSURE_GROUP halos; fluid_step_part(PRESSURE_GROUP) }  x (groups - 1)
+ *   fluid_step_part(VELOCITY_TAIL)    gradient subtraction (kernel.cu:326-355)
+ * (fluid_step and FLUID_PART_VELOCITY return FLUID_E_UNSUPPORTED on such a context: the exchanges
+ * are the caller's.)  With one group HEAD + TAIL == VELOCITY.  Same bits as the whole-domain run. */
+enum {
+  FLUID_PART_VELOCITY = 1,
+  FLUID_PART_DENSITY = 2,
+  FLUID_PART_VELOCITY_HEAD = 4,
+  FLUID_PART_PRESSURE_GROUP = 8,
+  FLUID_PART_VELOCITY_TAIL = 16
+};
 FLUID_API int fluid_step_part(fluid_ctx *ctx, int part);
 FLUID_API size_t fluid_halo_bytes_part(const fluid_ctx *ctx, int dir, int parts);
 FLUID_API int fluid_halo_pack_part(fluid_ctx *ctx, int dir, int part, void *dev_dst, void *stream);

@@ -17,11 +17,12 @@ def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     backend, n, J, steps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
     overlap = bool(int(sys.argv[5]))
+    groups = int(sys.argv[6]) if len(sys.argv) > 6 else 0
     dist.init_process_group(backend, rank=rank, world_size=world)
     pkg = fluid_amd_loader.load()
     from fluid_simulation_amd.slab import SlabSim
     sim = SlabSim(pkg, n, rank=rank, world=world, device_index=0, pressure_iters=J, halo_rows=2,
-                  overlap=overlap)
+                  overlap=overlap, pressure_groups=groups)
     ss = pkg.SplatStream()
     for s in range(steps):
         if s % 2 == 0:

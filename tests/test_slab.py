@@ -134,6 +134,83 @@ def test_slab_contexts_reject_what_they_cannot_do(pkg, hip):
     assert pkg.FluidSim(512, slab_rank=0, slab_count=4).halo_bytes(-1) == 0
 
 
+def test_slab_plan_with_pressure_groups(pkg, hip):
+    """J sweeps in G groups: halo_vel = Jg + 1 + D + A with Jg = ceil(J / G); halo_prs = Jg + 1
+    pressure rows travel between groups; a group count that would leave the last group empty is
+    reduced; one group (or a whole-domain context) exchanges no pressure."""
+    p = hip.slab_plan(8192, 3, 8, diffusion_iters=10, pressure_iters=200, pressure_groups=4)
+    assert (p["pressure_groups"], p["halo_prs"], p["halo_vel"]) == (4, 51, 50 + 1 + 10 + 8)
+    p1 = hip.slab_plan(8192, 3, 8, diffusion_iters=10, pressure_iters=200)
+    assert (p1["pressure_groups"], p1["halo_prs"], p1["halo_vel"]) == (1, 0, 219)
+    p = hip.slab_plan(1024, 0, 2, diffusion_iters=3, pressure_iters=10, pressure_groups=4)  # Jg = 3: 3+3+3+1
+    assert (p["pressure_groups"], p["halo_prs"]) == (4, 4)
+    p = hip.slab_plan(1024, 0, 2, diffusion_iters=3, pressure_iters=9, pressure_groups=6)   # Jg = 2: 5 groups
+    assert (p["pressure_groups"], p["halo_prs"]) == (5, 3)
+    p = hip.slab_plan(1024, 0, 2, diffusion_iters=3, pressure_iters=5, pressure_groups=50)  # at most J groups
+    assert (p["pressure_groups"], p["halo_prs"]) == (5, 2)
+    assert hip.slab_plan(512, 0, 1, pressure_groups=4)["pressure_groups"] == 1
+    # 8192^2, J = 200 on 8 GPUs only fits... both ways, but 16 slabs need the groups
+    with pytest.raises(pkg.FluidError):
+        hip.slab_plan(2048, 3, 16, pressure_iters=200)
+    assert hip.slab_plan(2048, 3, 16, pressure_iters=200, pressure_groups=4)["halo_vel"] == 69
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", [0, 4], ids=["fused", "unfused"])
+@pytest.mark.parametrize("count,n,D,J,A,G", [(2, 256, 10, 10, 1, 2), (4, 512, 10, 40, 8, 4), (3, 300, 3, 7, 2, 3),
+                                             (4, 1024, 10, 200, 8, 5), (2, 128, 2, 9, 1, 9)])
+def test_slabs_with_pressure_groups_equal_whole_domain(pkg, hip, count, n, D, J, A, G, flags):
+    """The grouped pressure loop (head, pressure-halo exchange + group, ..., tail) gives the bits of
+    the whole-domain run: uneven last groups, one sweep per group, temporal-blocking passes that
+    do not divide the group length."""
+    import fluid_simulation_amd.slab as slab
+    whole = pkg.FluidSim(n, diffusion_iters=D, pressure_iters=J, flags=flags)
+    group = slab.LocalSlabGroup(pkg, n, count, diffusion_iters=D, pressure_iters=J, halo_rows=A, flags=flags,
+                                pressure_groups=G)
+    assert group.groups > 1
+    ss_a, ss_b = pkg.SplatStream(), pkg.SplatStream()
+    for s in range(4):
+        if s % 2 == 0:
+            whole.add_source(*ss_a.splat())
+            group.add_source(*ss_b.splat())
+        whole.step(1)
+        group.step(1)
+    for f, fid in (("velocity", pkg.FIELD_VELOCITY), ("density", pkg.FIELD_DENSITY),
+                   ("pressure", pkg.FIELD_PRESSURE), ("divergence", pkg.FIELD_DIVERGENCE)):
+        assert_bit_equal(group.read(fid), whole.read(fid), f"{f} count={count} groups={G}")
+    s0 = group.sims[0]
+    with pytest.raises(pkg.FluidError):
+        s0.step(1)                         # the exchanges between groups are the caller's
+    with pytest.raises(pkg.FluidError):
+        s0.step_part(pkg.PART_PRESSURE_GROUP)  # no head yet in this step
+    group.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("overlap", [0, 1], ids=["plain", "overlap"])
+def test_slabsim_multiprocess_with_pressure_groups(overlap):
+    """SlabSim driving grouped pressure sweeps over a real process group (gloo, ranks share GPU 0)."""
+    world, port = 3, free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), GLOO_SOCKET_IFNAME="lo")
+        procs.append(subprocess.Popen(
+            [sys.executable, os.path.join(ROOT, "tests", "slab_gpu_worker.py"), "gloo", "384", "30", "4", str(overlap), "3"],
+            env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out)
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} failed:\n{out[-3000:]}"
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("overlap", [0, 1], ids=["plain", "overlap"])
 @pytest.mark.parametrize("world", [2, 4])

@@ -14,28 +14,43 @@ import fluid_amd_loader  # noqa: E402
 pkg = fluid_amd_loader.load()
 n, J, G = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 rank = int(sys.argv[4]) if len(sys.argv) > 4 else G // 2
-sim = pkg.FluidSim(n, pressure_iters=J, slab_rank=rank, slab_count=G)
+groups = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+sim = pkg.FluidSim(n, pressure_iters=J, slab_rank=rank, slab_count=G, pressure_groups=groups)
+
+
+def velocity_part():
+    if sim.pressure_groups <= 1:
+        sim.step_part(pkg.PART_VELOCITY)
+        return
+    sim.step_part(pkg.PART_VELOCITY_HEAD)
+    for _ in range(sim.pressure_groups - 1):
+        sim.step_part(pkg.PART_PRESSURE_GROUP)
+    sim.step_part(pkg.PART_VELOCITY_TAIL)
+
+
+
 ss = pkg.SplatStream()
 for _ in range(3):
     sim.add_source(*ss.splat())
 for _ in range(3):
-    sim.step(1)
+    velocity_part()
+    sim.step_part(pkg.PART_DENSITY)
 sim.sync()
-for mode in ("whole", "parts"):
+for mode in (("whole", "parts") if sim.pressure_groups <= 1 else ("parts",)):
     steps = 20
     t0 = time.perf_counter()
     for _ in range(steps):
         if mode == "whole":
             sim.step(1)
         else:
-            sim.step_part(pkg.PART_VELOCITY)
+            velocity_part()
             sim.step_part(pkg.PART_DENSITY)
     try:
         sim.sync()
     except Exception as e:  # stale halos may trip the halo flag; timing is still valid
         print("sync:", e)
     dt = (time.perf_counter() - t0) / steps * 1e3
-    print(json.dumps({"n": n, "J": J, "slabs": G, "rank": rank, "rows": sim.rows, "mode": mode,
+    print(json.dumps({"n": n, "J": J, "slabs": G, "rank": rank, "rows": sim.rows, "groups": sim.pressure_groups, "mode": mode,
                       "ms_per_step": round(dt, 4), "GCUPS_whole_job_if_all_like_this": round(n * n / dt / 1e6, 2)}), flush=True)
 try:
     st = sim.profile_steps(1)
