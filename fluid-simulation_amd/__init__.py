@@ -11,7 +11,8 @@ library or without a GPU raises.  Nothing in this package imports ``oracle/``.
 from .capi import (FluidLib, FluidSim, FluidError, FluidParams, KernelStat, SlabInfo, hip_lib_path,
                    FIELD_VELOCITY, FIELD_DENSITY, FIELD_PRESSURE, FIELD_DIVERGENCE,
                    FIELD_VORTICITY, FLAG_VORTICITY, FLAG_NO_GRAPH, FLAG_UNFUSED, ABI_SYMBOLS, PART_VELOCITY, PART_DENSITY,
-                   PART_VELOCITY_HEAD, PART_PRESSURE_GROUP, PART_VELOCITY_TAIL)
+                   PART_VELOCITY_HEAD, PART_PRESSURE_GROUP, PART_VELOCITY_TAIL,
+                   PART_TAIL_DENSITY_EDGES, PART_TAIL_DENSITY_INTERIOR)
 from . import viz, replay as replay_mod
 from .replay import replay, parse_events
 from .splats import SplatStream, COLOR_PRESETS, alg_bytes_per_cell, run_seeded, DEFAULT_SEED
@@ -21,5 +22,6 @@ __all__ = [
     "FIELD_VELOCITY", "FIELD_DENSITY", "FIELD_PRESSURE", "FIELD_DIVERGENCE", "FIELD_VORTICITY",
     "FLAG_VORTICITY", "FLAG_NO_GRAPH", "FLAG_UNFUSED", "ABI_SYMBOLS", "PART_VELOCITY", "PART_DENSITY",
     "PART_VELOCITY_HEAD", "PART_PRESSURE_GROUP", "PART_VELOCITY_TAIL",
+    "PART_TAIL_DENSITY_EDGES", "PART_TAIL_DENSITY_INTERIOR",
     "viz", "replay", "parse_events", "SplatStream", "COLOR_PRESETS", "alg_bytes_per_cell", "run_seeded", "DEFAULT_SEED",
 ]

@@ -40,6 +40,7 @@ struct fluid_ctx {
   int halo_vel = 0, halo_dens = 0, adv_rows = 0;  // slab halos (fluid_slab_plan); 0 when whole-domain
   int groups = 1, jg = 0, halo_prs = 0;  // pressure groups: count, sweeps per group, rows exchanged
   int pgroup = 0;                        // next pressure group to run in the current step
+  bool tail_edges_done = false;          // FLUID_PART_TAIL_DENSITY_EDGES ran, INTERIOR pending
   bool slab = false, has_lo = false, has_hi = false;
   float2 *vel[2] = {nullptr, nullptr};   // velocityBufferArray[2]  kernel.cu:443-444
   float4 *dens[2] = {nullptr, nullptr};  // densityBufferArray[2]   kernel.cu:447-448
@@ -304,6 +305,32 @@ void enq_gradient(fluid_ctx *c, bool with_density) {
   c->vin ^= 1;
 }
 
+// The fused gradient subtraction + density advection on a sub-range of the owned rows: the rows
+// within halo_vel of a neighbouring slab (edges: what the next exchange sends) or the rest.
+void enq_gradient_density_rows(fluid_ctx *c, bool edges) {
+  const Range own = widened(c, 0);
+  const int h = c->halo_vel < own.r1 - own.r0 ? c->halo_vel : own.r1 - own.r0;
+  const int lo_end = c->has_lo ? own.r0 + h : own.r0;                       // [own.r0, lo_end)
+  const int hi_beg = c->has_hi ? (own.r1 - h > lo_end ? own.r1 - h : lo_end) : own.r1;  // [hi_beg, own.r1)
+  const Range valid = c->slab ? widened(c, c->halo_dens) : Range{0, c->g.L};
+  // EDGES reads the current buffers and writes the other halves, then flips; INTERIOR runs after
+  // the flip, so its input is the other half and its output the current one.
+  const int vi = edges ? c->vin : c->vin ^ 1, di = edges ? c->din : c->din ^ 1;
+  const Range parts[2] = {edges ? Range{own.r0, lo_end} : Range{lo_end, hi_beg},
+                          edges ? Range{hi_beg, own.r1} : Range{0, 0}};
+  for (const Range &r : parts) {
+    if (r.r1 <= r.r0) continue;
+    ProfScope p(c, K_PROJECT_ADVECT_DENS, 60.0 * (double)c->g.n * (r.r1 - r.r0));
+    launch_project_advect_dens(c->stream, c->g, r.r0, r.r1, valid.r0, valid.r1, c->prm.dt,
+                               c->vel[vi], c->prs[c->pin], c->vel[vi ^ 1], c->dens[di],
+                               c->dens[di ^ 1], c->halo_flag);
+  }
+  if (edges) {
+    c->vin ^= 1;
+    c->din ^= 1;
+  }
+}
+
 void enq_project(fluid_ctx *c, bool with_density = false) {  // one group: the whole projection()
   enq_pressure_group(c, 0);
   enq_gradient(c, with_density);
@@ -342,6 +369,8 @@ void enq_step(fluid_ctx *c, int parts) {
   if (parts & FLUID_PART_VELOCITY_HEAD) enq_velocity_head(c);
   if (parts & FLUID_PART_PRESSURE_GROUP) enq_pressure_group(c, c->pgroup);
   if (parts & FLUID_PART_VELOCITY_TAIL) enq_gradient(c, false);
+  if (parts & FLUID_PART_TAIL_DENSITY_EDGES) enq_gradient_density_rows(c, true);
+  if (parts & FLUID_PART_TAIL_DENSITY_INTERIOR) enq_gradient_density_rows(c, false);
   if (parts & FLUID_PART_DENSITY) enq_advect_density(c);
 }
 
@@ -360,7 +389,7 @@ int run_steps(fluid_ctx *c, int nsteps, int parts = FLUID_PART_VELOCITY | FLUID_
       if (rc) return rc;
       continue;
     }
-    const int key = state_of(c) | (parts << 3) | (c->pgroup << 8);
+    const int key = state_of(c) | (parts << 3) | (c->pgroup << 12);
     auto it = c->graphs.find(key);
     if (it == c->graphs.end()) {
       GraphEntry ge;
@@ -743,7 +772,11 @@ int fluid_step_part(fluid_ctx *c, int part) {
       if (c->pgroup < 1 || c->pgroup >= c->groups) return fail(c, FLUID_E_INVALID, "no pressure group pending");
       break;
     case FLUID_PART_VELOCITY_TAIL:
+    case FLUID_PART_TAIL_DENSITY_EDGES:
       if (c->pgroup != c->groups) return fail(c, FLUID_E_INVALID, "pressure groups not finished");
+      break;
+    case FLUID_PART_TAIL_DENSITY_INTERIOR:
+      if (!c->tail_edges_done) return fail(c, FLUID_E_INVALID, "FLUID_PART_TAIL_DENSITY_EDGES must run first");
       break;
     default:
       return FLUID_E_INVALID;
@@ -754,6 +787,8 @@ int fluid_step_part(fluid_ctx *c, int part) {
   if (part == FLUID_PART_VELOCITY_HEAD) c->pgroup = 1;
   else if (part == FLUID_PART_PRESSURE_GROUP) ++c->pgroup;
   else if (part == FLUID_PART_VELOCITY_TAIL) c->pgroup = 0;
+  else if (part == FLUID_PART_TAIL_DENSITY_EDGES) { c->pgroup = 0; c->tail_edges_done = true; }
+  else if (part == FLUID_PART_TAIL_DENSITY_INTERIOR) c->tail_edges_done = false;
   return FLUID_OK;
 }
 

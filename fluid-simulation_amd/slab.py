@@ -98,12 +98,17 @@ class SlabSim:
     ``gather`` assembles the whole field on rank 0.
 
     ``overlap=True`` (default; env FLUID_SLAB_OVERLAP=0 turns it off) hides the halo traffic
-    behind compute: the step is run as its two parts (include/fluid.h fluid_step_part), and
+    behind compute (include/fluid.h fluid_step_part).  The step ends with the fused gradient
+    subtraction + density advection run in two launches: first the edge rows the neighbours need,
+    then the interior; both halo messages for step s+1 are posted between the two on a second
+    stream, so
 
-        velocity halos for step s+1 travel while step s's density advection runs,
-        density halos for step s+1 travel while step s+1's velocity part runs,
+        velocity halos for step s+1 travel while step s's interior rows are finished,
+        density halos for step s+1 travel until step s+1's last kernel needs them.
 
-    on a second stream.  Same messages, same results; only when they move differs.
+    (With FLUID_FLAG_UNFUSED the two stages are separate kernels: velocity halos then travel during
+    the density advection, density halos during the next velocity part.)  Same messages, same
+    results; only when they move differs.
     """
 
     def __init__(self, pkg, n: int, *, rank: int, world: int, device_index: int = 0, group=None,
@@ -123,14 +128,16 @@ class SlabSim:
         self.V, self.D = pkg.PART_VELOCITY, pkg.PART_DENSITY
         self.P = pkg.PART_PRESSURE_GROUP
         self.groups = self.sim.pressure_groups
+        self.split_tail = not (params.get("flags", 0) & pkg.FLAG_UNFUSED)
 
-    def _velocity_part(self):
-        """The velocity part on the compute stream.  With pressure groups (deep Jacobi loops on
-        short slabs) the sweeps run group by group with an exchange of pressure halo rows in
-        between; those exchanges are on the critical path."""
+    def _velocity_part(self, tail=True):
+        """The velocity part on the compute stream (``tail=False``: without the gradient
+        subtraction).  With pressure groups (deep Jacobi loops on short slabs) the sweeps run
+        group by group with an exchange of pressure halo rows in between; those exchanges are on
+        the critical path."""
         sim = self.sim
         with self.torch.cuda.stream(self.stream):
-            if self.groups <= 1:
+            if self.groups <= 1 and tail:
                 sim.step_part(self.V)
                 return
             sim.step_part(self.pkg.PART_VELOCITY_HEAD)
@@ -139,8 +146,9 @@ class SlabSim:
             self._finish(self.P)
             with self.torch.cuda.stream(self.stream):
                 sim.step_part(self.P)
-        with self.torch.cuda.stream(self.stream):
-            sim.step_part(self.pkg.PART_VELOCITY_TAIL)
+        if tail:
+            with self.torch.cuda.stream(self.stream):
+                sim.step_part(self.pkg.PART_VELOCITY_TAIL)
 
     # -- exchanges -------------------------------------------------------------------------
     def _start(self, part):
@@ -186,6 +194,17 @@ class SlabSim:
                 self._start(V)
             if not self.ex.in_flight(D):
                 self._start(D)
+            if self.split_tail:
+                self._finish(V)
+                self._velocity_part(tail=False)
+                self._finish(D)
+                with self.torch.cuda.stream(self.stream):
+                    sim.step_part(self.pkg.PART_TAIL_DENSITY_EDGES)
+                self._start(V)    # the new edge rows travel while the interior rows are computed
+                self._start(D)
+                with self.torch.cuda.stream(self.stream):
+                    sim.step_part(self.pkg.PART_TAIL_DENSITY_INTERIOR)
+                continue
             self._finish(V)
             self._velocity_part()
             self._start(V)        # next step's velocity halos: travel during the density part
@@ -218,73 +237,95 @@ class SlabSim:
 class LocalSlabGroup:
     """All slabs of one domain as separate contexts on ONE device, halos moved by handing each
     slab its neighbour's packed send buffer.  Exercises exactly the library's slab path (plan,
-    margins, pack/unpack) without a second GPU; used by the GPU tests to demand bit-identical
-    results to the whole-domain context."""
+    margins, pack/unpack, step parts) without a second GPU; used by the GPU tests to demand
+    bit-identical results to the whole-domain context.
 
-    def __init__(self, pkg, n: int, count: int, device_index: int = 0, **params):
+    ``split_tail=True`` drives the step the way SlabSim's overlap mode does: the fused gradient
+    subtraction + density advection in two launches (edge rows, then interior), with the halo
+    blocks for the next step packed between the two."""
+
+    def __init__(self, pkg, n: int, count: int, device_index: int = 0, split_tail: bool = False, **params):
         import torch
-        self.pkg, self.count = pkg, count
+        self.pkg, self.count, self.split_tail = pkg, count, split_tail
         self.sims = [pkg.FluidSim(n, device=device_index, slab_rank=r, slab_count=count, **params)
                      for r in range(count)]
-        dev = torch.device("cuda", device_index)
-        mk = lambda nbytes: torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
-        self.send = [{-1: mk(s.halo_bytes(-1)), +1: mk(s.halo_bytes(+1))} for s in self.sims]
         self.groups = self.sims[0].pressure_groups
+        dev = torch.device("cuda", device_index)
+        self._mk = lambda nbytes: torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+        self._bufs = {}
+        self.early_valid = False   # halo blocks packed between the edge and interior launches
 
-    def _exchange_part(self, part):
+    def _buf(self, part, r, d):
+        key = (part, r, d)
+        if key not in self._bufs:
+            self._bufs[key] = self._mk(self.sims[r].halo_bytes_part(d, part))
+        return self._bufs[key]
+
+    def _sync(self):
+        for s in self.sims:
+            s.sync()  # contexts have their own streams: packs must land before unpacks read
+
+    def _pack(self, part):
         for r, s in enumerate(self.sims):
             for d in (-1, +1):
                 if s.halo_bytes_part(d, part):
-                    s.halo_pack_part(d, part, self.send[r][d].data_ptr(), None)
-        for s in self.sims:
-            s.sync()
+                    s.halo_pack_part(d, part, self._buf(part, r, d).data_ptr(), None)
+
+    def _unpack(self, part):
+        self._sync()
         for r, s in enumerate(self.sims):
             if s.halo_bytes_part(-1, part):
-                s.halo_unpack_part(-1, part, self.send[r - 1][+1].data_ptr(), None)
+                s.halo_unpack_part(-1, part, self._buf(part, r - 1, +1).data_ptr(), None)
             if s.halo_bytes_part(+1, part):
-                s.halo_unpack_part(+1, part, self.send[r + 1][-1].data_ptr(), None)
-        for s in self.sims:
-            s.sync()
+                s.halo_unpack_part(+1, part, self._buf(part, r + 1, -1).data_ptr(), None)
+        self._sync()
 
     def add_source(self, *a, **k):
+        self.early_valid = False   # blocks packed before the splat are stale
         for s in self.sims:
             s.add_source(*a, **k)
 
+    def _each(self, part):
+        for s in self.sims:
+            s.step_part(part)
+
     def step(self, nsteps: int = 1):
+        pkg = self.pkg
+        V, D, P = pkg.PART_VELOCITY, pkg.PART_DENSITY, pkg.PART_PRESSURE_GROUP
         for _ in range(nsteps):
-            for r, s in enumerate(self.sims):
-                for d in (-1, +1):
-                    if s.halo_bytes(d):
-                        s.halo_pack(d, self.send[r][d].data_ptr())
-            for s in self.sims:
-                s.sync()  # contexts have their own streams: packs must land before unpacks read
-            for r, s in enumerate(self.sims):
-                if s.halo_bytes(-1):
-                    s.halo_unpack(-1, self.send[r - 1][+1].data_ptr())
-                if s.halo_bytes(+1):
-                    s.halo_unpack(+1, self.send[r + 1][-1].data_ptr())
-            if self.groups <= 1:
+            if not self.early_valid:
+                self._pack(V)
+                self._pack(D)
+            self._unpack(V)
+            self._unpack(D)
+            self.early_valid = False
+            if self.groups <= 1 and not self.split_tail:
                 for s in self.sims:
                     s.step(1)
+                self._sync()
+                continue
+            self._each(pkg.PART_VELOCITY_HEAD)
+            for _g in range(self.groups - 1):
+                self._pack(P)
+                self._unpack(P)
+                self._each(P)
+            if self.split_tail:
+                self._each(pkg.PART_TAIL_DENSITY_EDGES)
+                self._pack(V)      # the new edge rows, while the interior rows are still pending
+                self._pack(D)
+                self.early_valid = True
+                self._each(pkg.PART_TAIL_DENSITY_INTERIOR)
             else:
-                P = self.pkg.PART_PRESSURE_GROUP
-                for s in self.sims:
-                    s.step_part(self.pkg.PART_VELOCITY_HEAD)
-                for _ in range(self.groups - 1):
-                    self._exchange_part(P)
-                    for s in self.sims:
-                        s.step_part(P)
-                for s in self.sims:
-                    s.step_part(self.pkg.PART_VELOCITY_TAIL)
-                    s.step_part(self.pkg.PART_DENSITY)
-            for s in self.sims:
-                s.sync()
+                self._each(pkg.PART_VELOCITY_TAIL)
+                self._each(D)
+            self._sync()
 
     def read(self, field):
         import numpy as np
         return np.concatenate([s.read(field) for s in self.sims], axis=0)
 
     def write(self, field, arr):
+        self.early_valid = False
         for s in self.sims:
             s.write(field, arr[s.row0:s.row0 + s.rows])
 

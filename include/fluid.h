@@ -236,7 +236,13 @@ enum {
   FLUID_PART_DENSITY = 2,
   FLUID_PART_VELOCITY_HEAD = 4,
   FLUID_PART_PRESSURE_GROUP = 8,
-  FLUID_PART_VELOCITY_TAIL = 16
+  FLUID_PART_VELOCITY_TAIL = 16,
+  /* VELOCITY_TAIL + DENSITY as the one fused kernel, in two launches: first the owned rows that
+   * the next exchange sends (within halo_vel rows of a neighbouring slab), then the rest, so that
+   * both halo messages travel while the interior is computed.  EDGES flips the current buffers:
+   * after it fluid_halo_pack_part sends the new edge rows. */
+  FLUID_PART_TAIL_DENSITY_EDGES = 32,
+  FLUID_PART_TAIL_DENSITY_INTERIOR = 64
 };
 FLUID_API int fluid_step_part(fluid_ctx *ctx, int part);
 FLUID_API size_t fluid_halo_bytes_part(const fluid_ctx *ctx, int dir, int parts);

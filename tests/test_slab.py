@@ -95,6 +95,32 @@ def test_slabs_equal_whole_domain(pkg, hip, count, n, D, J, A, flags):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("count,n,D,J,A,G", [(2, 256, 10, 10, 1, 0), (4, 512, 10, 40, 8, 0), (3, 300, 3, 7, 2, 2),
+                                             (8, 1024, 10, 40, 8, 0), (2, 64, 2, 3, 1, 0), (4, 128, 10, 10, 8, 0)])
+def test_slabs_with_split_tail_equal_whole_domain(pkg, hip, count, n, D, J, A, G):
+    """The step as the overlapped multi-GPU driver runs it — fused gradient subtraction + density
+    advection on the edge rows, halo blocks packed, then the interior rows — gives the bits of the
+    whole-domain run, also when the two edges cover the whole slab (interior empty)."""
+    import fluid_simulation_amd.slab as slab
+    whole = pkg.FluidSim(n, diffusion_iters=D, pressure_iters=J)
+    group = slab.LocalSlabGroup(pkg, n, count, split_tail=True, diffusion_iters=D, pressure_iters=J,
+                                halo_rows=A, pressure_groups=G)
+    ss_a, ss_b = pkg.SplatStream(), pkg.SplatStream()
+    for s in range(7):
+        if s % 3 == 0:
+            whole.add_source(*ss_a.splat())
+            group.add_source(*ss_b.splat())
+        whole.step(1)
+        group.step(1)
+    for f, fid in (("velocity", pkg.FIELD_VELOCITY), ("density", pkg.FIELD_DENSITY),
+                   ("pressure", pkg.FIELD_PRESSURE), ("divergence", pkg.FIELD_DIVERGENCE)):
+        assert_bit_equal(group.read(fid), whole.read(fid), f"{f} count={count}")
+    with pytest.raises(pkg.FluidError):
+        group.sims[0].step_part(pkg.PART_TAIL_DENSITY_INTERIOR)  # no edges launch pending
+    group.close()
+
+
+@pytest.mark.gpu
 def test_slabs_long_backtraces_and_halo_violation(pkg, hip):
     """Backtraces of several rows are fine while they stay within halo_rows; one that leaves it
     must be reported (FLUID_E_HALO), never silently wrong."""

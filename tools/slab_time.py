@@ -18,14 +18,15 @@ groups = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 sim = pkg.FluidSim(n, pressure_iters=J, slab_rank=rank, slab_count=G, pressure_groups=groups)
 
 
-def velocity_part():
-    if sim.pressure_groups <= 1:
+def velocity_part(tail=True):
+    if sim.pressure_groups <= 1 and tail:
         sim.step_part(pkg.PART_VELOCITY)
         return
     sim.step_part(pkg.PART_VELOCITY_HEAD)
     for _ in range(sim.pressure_groups - 1):
         sim.step_part(pkg.PART_PRESSURE_GROUP)
-    sim.step_part(pkg.PART_VELOCITY_TAIL)
+    if tail:
+        sim.step_part(pkg.PART_VELOCITY_TAIL)
 
 
 
@@ -36,12 +37,16 @@ for _ in range(3):
     velocity_part()
     sim.step_part(pkg.PART_DENSITY)
 sim.sync()
-for mode in (("whole", "parts") if sim.pressure_groups <= 1 else ("parts",)):
+for mode in (("whole", "parts", "split") if sim.pressure_groups <= 1 else ("parts", "split")):
     steps = 20
     t0 = time.perf_counter()
     for _ in range(steps):
         if mode == "whole":
             sim.step(1)
+        elif mode == "split":
+            velocity_part(tail=False)
+            sim.step_part(pkg.PART_TAIL_DENSITY_EDGES)
+            sim.step_part(pkg.PART_TAIL_DENSITY_INTERIOR)
         else:
             velocity_part()
             sim.step_part(pkg.PART_DENSITY)
