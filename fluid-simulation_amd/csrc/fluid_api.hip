@@ -50,6 +50,7 @@ struct fluid_ctx {
   int vin = 0, din = 0, pin = 0;  // inputVelocityBuffer / inputDensityBuffer / inputPressureBuffer
   int *halo_flag = nullptr;       // device word: advection left the stored rows
   void *dump = nullptr;           // one row (n * 16 B): sink for rows a TB wave must not store
+  char *arena = nullptr;          // the seven field buffers live in one allocation (fluid_init)
   float alpha = 0.f, beta = 0.f;  // diffusion constants, kernel.cu:182-183
   hipStream_t own_stream = nullptr, stream = nullptr;
   std::map<int, GraphEntry> graphs;
@@ -541,18 +542,32 @@ int fluid_init(fluid_ctx **out, const fluid_params *p) {
     HIPCHK(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     const size_t nc = cells_local(c);
-    for (int i = 0; i < 2; ++i) {
-      HIPCHK(c, hipMalloc(&c->vel[i], nc * sizeof(float2)));
-      HIPCHK(c, hipMalloc(&c->dens[i], nc * sizeof(float4)));
-      HIPCHK(c, hipMalloc(&c->prs[i], nc * sizeof(float)));
+    // One arena for the seven fields.  FLUID_ARENA_SKEW (bytes, experiments only) offsets each
+    // field's base against the others; swept from 256 B to 3 MiB on MI355X (tools/skew_sweep.py)
+    // it has no reproducible effect — what does move the 16384^2 step by about 3 % from one
+    // context to the next is where the driver places the arena physically.
+    {
+      const size_t skew = (size_t)env_int("FLUID_ARENA_SKEW", 0) & ~(size_t)255;
+      const size_t sizes[7] = {nc * sizeof(float2), nc * sizeof(float2), nc * sizeof(float4), nc * sizeof(float4),
+                               nc * sizeof(float), nc * sizeof(float), nc * sizeof(float)};
+      size_t off[7], total = 0;
+      for (int k = 0; k < 7; ++k) {
+        off[k] = total + k * skew;
+        total += (sizes[k] + 255) & ~(size_t)255;
+      }
+      total += 7 * skew;
+      HIPCHK(c, hipMalloc(&c->arena, total));
       // The reference zeroes only the current halves (kernel.cu:518-528); the
       // others are fully overwritten before first read.  Zero all: it is free.
-      HIPCHK(c, hipMemsetAsync(c->vel[i], 0, nc * sizeof(float2), c->stream));
-      HIPCHK(c, hipMemsetAsync(c->dens[i], 0, nc * sizeof(float4), c->stream));
-      HIPCHK(c, hipMemsetAsync(c->prs[i], 0, nc * sizeof(float), c->stream));
+      HIPCHK(c, hipMemsetAsync(c->arena, 0, total, c->stream));
+      c->vel[0] = (float2 *)(c->arena + off[0]);
+      c->vel[1] = (float2 *)(c->arena + off[1]);
+      c->dens[0] = (float4 *)(c->arena + off[2]);
+      c->dens[1] = (float4 *)(c->arena + off[3]);
+      c->prs[0] = (float *)(c->arena + off[4]);
+      c->prs[1] = (float *)(c->arena + off[5]);
+      c->div = (float *)(c->arena + off[6]);
     }
-    HIPCHK(c, hipMalloc(&c->div, nc * sizeof(float)));
-    HIPCHK(c, hipMemsetAsync(c->div, 0, nc * sizeof(float), c->stream));
     HIPCHK(c, hipMalloc(&c->dump, (size_t)prm.n * 16 + 256));
     HIPCHK(c, hipMalloc(&c->halo_flag, 256));
     HIPCHK(c, hipMemsetAsync(c->halo_flag, 0, 256, c->stream));
@@ -577,12 +592,7 @@ void fluid_destroy(fluid_ctx *c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   drop_graphs(c);
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
-  for (int i = 0; i < 2; ++i) {
-    if (c->vel[i]) (void)hipFree(c->vel[i]);
-    if (c->dens[i]) (void)hipFree(c->dens[i]);
-    if (c->prs[i]) (void)hipFree(c->prs[i]);
-  }
-  if (c->div) (void)hipFree(c->div);
+  if (c->arena) (void)hipFree(c->arena);
   if (c->vort) (void)hipFree(c->vort);
   if (c->halo_flag) (void)hipFree(c->halo_flag);
   if (c->dump) (void)hipFree(c->dump);
