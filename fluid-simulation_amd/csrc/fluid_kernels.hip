@@ -304,11 +304,20 @@ __global__ __launch_bounds__(BX *BY) void k_project(Geom g, int r0, int r1,
 // projection (kernel.cu:326-355) and density advection (kernel.cu:142-165) of the same cell in one
 // pass: the density backtrace starts from the projected velocity of its own cell only, so the
 // value just computed is used instead of being written out and read back (8 B/cell less).
-__global__ __launch_bounds__(BX *BY) void k_project_advect_dens(
+#ifndef FUSED_BY
+#define FUSED_BY 4
+#endif
+constexpr int TAIL_BY = FUSED_BY;  // rows per block of the fused kernel
+__global__ __launch_bounds__(BX *TAIL_BY) void k_project_advect_dens(
     Geom g, int r0, int r1, Valid valid, float dt, const float2 *__restrict__ vin,
     const float *__restrict__ p, float2 *__restrict__ vout, const float4 *__restrict__ din,
     float4 *__restrict__ dout, int *flag) {
-  CELL_PROLOGUE
+  const int x = blockIdx.x * BX + threadIdx.x;
+  const int r = r0 + blockIdx.y * TAIL_BY + threadIdx.y;
+  if (x >= g.n || r >= r1) return;
+  const int y = g.ybase + r;
+  const size_t id = (size_t)r * g.n + x;
+  const bool interior = x > 0 && x < g.n - 1 && y > 0 && y < g.n - 1;
   const float2 v = project_cell(g, x, y, r, id, interior, vin, p);
   vout[id] = v;
   float px = (float)x - dt * v.x;
@@ -410,8 +419,8 @@ void launch_project_advect_dens(hipStream_t s, Geom g, int r0, int r1, int vlo, 
                                 const float2 *vin, const float *p, float2 *vout, const float4 *din,
                                 float4 *dout, int *flag) {
   if (r1 <= r0) return;
-  hipLaunchKernelGGL(k_project_advect_dens, grid_for(g, r0, r1), kBlock, 0, s, g, r0, r1, Valid{vlo, vhi}, dt,
-                     vin, p, vout, din, dout, flag);
+  hipLaunchKernelGGL(k_project_advect_dens, dim3((g.n + BX - 1) / BX, (r1 - r0 + TAIL_BY - 1) / TAIL_BY),
+                     dim3(BX, TAIL_BY), 0, s, g, r0, r1, Valid{vlo, vhi}, dt, vin, p, vout, din, dout, flag);
 }
 void launch_advect_dens(hipStream_t s, Geom g, int r0, int r1, int vlo, int vhi, float dt,
                         const float2 *vel, const float4 *din, float4 *dout, int *flag) {
