@@ -288,9 +288,9 @@ class FluidSim:
         return ms.value
 
     def profile_steps(self, nsteps: int):
-        stats = (KernelStat * 16)()
+        stats = (KernelStat * 32)()
         cnt = C.c_int()
-        self._chk(self.lib.dll.fluid_profile_steps(self._h, nsteps, stats, 16, C.byref(cnt)),
+        self._chk(self.lib.dll.fluid_profile_steps(self._h, nsteps, stats, 32, C.byref(cnt)),
                   "fluid_profile_steps")
         return [dict(name=stats[i].name.decode(), launches=stats[i].launches,
                      total_ms=stats[i].total_ms, alg_bytes=stats[i].alg_bytes)

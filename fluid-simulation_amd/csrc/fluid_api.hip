@@ -56,6 +56,7 @@ struct fluid_ctx {
   std::map<int, GraphEntry> graphs;
   // temporal-blocking plan (fused path): sweeps per launch, columns per lane, target waves
   int tb_kj = 10, tb_kd = 5, tb_cj = 2, tb_cd = 2, tb_waves = 8192, tb_minchunk = 4;
+  bool tile = false;  // small grids: LDS-tiled sweeps (fluid_kernels_tile.hip) instead of the register pipeline
   bool prof = false;
   std::vector<hipEvent_t> ev_pool;
   size_t ev_used = 0;
@@ -157,13 +158,13 @@ int env_int(const char *name, int dflt) {
 // Next launch's sweep count: split `left` sweeps into the fewest launches the instantiated
 // counts (fluid_kernels_tb.hip tb_has_k) allow with none above kmax, and among those the most
 // even split (40 with kmax 14 -> 14 + 13 + 13, not 14 + 14 + 10 + 2).
-int next_pass(int left, int kmax, int cols, bool float2_field) {
+int next_pass(int left, int kmax, int cols, bool float2_field, bool tile = false) {
   if (left <= 1) return 1;
   std::vector<int> cnt(left + 1, 1 << 20), big(left + 1, 0), pick(left + 1, 1);
   cnt[0] = 0;
   for (int j = 1; j <= left; ++j)
     for (int k = 1; k <= kmax && k <= j; ++k) {
-      if (!tb_has_k(k, cols, float2_field)) continue;
+      if (!(tile ? tile_has_k(k, float2_field) : tb_has_k(k, cols, float2_field))) continue;
       const int c = cnt[j - k] + 1, m = big[j - k] > k ? big[j - k] : k;
       if (c < cnt[j] || (c == cnt[j] && m < big[j])) { cnt[j] = c; big[j] = m; pick[j] = k; }
     }
@@ -192,6 +193,17 @@ bool use_tb(const fluid_ctx *c, int cols) {
 // sweep with `left` sweeps still to come must cover out_m + left.
 void enq_diffuse(fluid_ctx *c, int out_m) {
   const double cells = (double)cells_owned(c);
+  if (c->tile && !(c->prm.flags & FLUID_FLAG_UNFUSED)) {
+    for (int left = c->prm.diffusion_iters; left > 0;) {
+      const int k = next_pass(left, c->tb_kd, 0, true, true);
+      ProfScope p(c, K_DIFFUSE_TILE, 16.0 * k * cells);
+      const Range r = widened(c, out_m + left - k);
+      launch_diffuse_tile(c->stream, c->g, r.r0, r.r1, k, c->alpha, c->beta, c->vel[c->vin], c->vel[c->vin ^ 1]);
+      c->vin ^= 1;
+      left -= k;
+    }
+    return;
+  }
   if (use_tb(c, c->tb_cd)) {
     for (int left = c->prm.diffusion_iters; left > 0;) {
       const int k = next_pass(left, c->tb_kd, c->tb_cd, true);
@@ -242,6 +254,33 @@ void enq_pressure_group(fluid_ctx *c, int g) {
   const int first = g * glen, last = first + glen < J ? first + glen : J;
   int left = last - first;  // sweeps of this group
   const bool tb = use_tb(c, c->tb_cj);
+  const bool tile = c->tile && !(c->prm.flags & FLUID_FLAG_UNFUSED);
+  if (tile) {  // small grids: LDS-tiled sweeps, same ranges as the register pipeline below
+    const int div_m = c->groups > 1 ? glen : -1;
+    bool first = g == 0;
+    while (left > 0) {
+      const int k = next_pass(left, c->tb_kj, 0, false, true);
+      if (first) {
+        ProfScope p(c, K_JACOBI_DIV_TILE, 12.0 * cells + 12.0 * k * cells);
+        const Range r = widened(c, div_m >= 0 ? div_m : 1 + left - k);
+        launch_jacobi_div_tile(c->stream, c->g, r.r0, r.r1, k, c->vel[c->vin], c->div, c->prs[c->pin ^ 1]);
+      } else {
+        ProfScope p(c, K_JACOBI_TILE, 12.0 * k * cells);
+        const Range r = widened(c, 1 + left - k);
+        launch_jacobi_tile(c->stream, c->g, r.r0, r.r1, k, c->prs[c->pin], c->div, c->prs[c->pin ^ 1]);
+      }
+      first = false;
+      c->pin ^= 1;
+      left -= k;
+    }
+    if (first) {  // J == 0: still the divergence and the pressure clear
+      ProfScope p(c, K_DIVERGENCE, 12.0 * cells);
+      const Range r = widened(c, div_m >= 0 ? div_m : J);
+      launch_divergence(c->stream, c->g, r.r0, r.r1, c->vel[c->vin], c->div);
+      (void)hipMemsetAsync(c->prs[c->pin], 0, cells_local(c) * sizeof(float), c->stream);
+    }
+    return;
+  }
   if (g == 0) {
     // the divergence must cover what every later group's first sweep reads: glen rows beyond
     const int div_m = c->groups > 1 ? glen : -1;
@@ -517,7 +556,9 @@ int fluid_init(fluid_ctx **out, const fluid_params *p) {
   c->has_hi = si.has_hi;
   // tuning knobs (defaults chosen from measurements); results do not depend on them
   // Plan by owned cells, from sweeps on MI355X (tools/tb_sweep.py, tools/small_sweep.py):
-  //   <= ~1024^2 : launch/latency bound -> short pipelines, as many waves as possible
+  //   <= ~1024^2 : launch/latency bound -> LDS tiles (fluid_kernels_tile.hip), 8 / 5 sweeps per
+  //                launch: 0.156 -> 0.112 ms at 1024^2, 0.106 -> 0.069 ms at 512^2 against the
+  //                register pipeline (which wins again from ~1500^2 up); FLUID_TILE=0/1 overrides
   //   ~2048^2    : 8 sweeps per launch
   //   ~4096^2 and the slabs of a 16384^2 domain on 8 GPUs: 10 sweeps per launch, and just under
   //                one resident round of waves (4 per SIMD x 1024 SIMDs): a few blocks over the
@@ -525,7 +566,9 @@ int fluid_init(fluid_ctx **out, const fluid_params *p) {
   //   >= 8192^2  : HBM round trips dominate -> 13-14 Jacobi / 10 diffusion sweeps per launch,
   //                twice the waves (shorter chunks even out the tail of the launch)
   const long long owned = (long long)prm.n * si.rows;
-  if (owned < (1ll << 21)) { c->tb_kj = 4; c->tb_minchunk = 1; }
+  c->tile = env_int("FLUID_TILE", owned < (1ll << 21) ? 1 : 0) != 0;
+  if (c->tile) { c->tb_kj = 8; c->tb_kd = 5; }
+  else if (owned < (1ll << 21)) { c->tb_kj = 4; c->tb_minchunk = 1; }
   else if (owned <= (1ll << 23)) { c->tb_kj = 8; c->tb_minchunk = 1; }
   else if (owned < (1ll << 26)) { c->tb_kd = 10; c->tb_waves = 3900; c->tb_minchunk = 1; }
   else { c->tb_kd = 10; c->tb_kj = 14; c->tb_waves = 16384; c->tb_minchunk = 1; }

@@ -28,6 +28,9 @@ enum KernelId {
   K_JACOBI_TB,    // temporally blocked Jacobi
   K_JACOBI_DIV_TB,  // divergence + pressure clear + first Jacobi launch
   K_PROJECT_ADVECT_DENS,  // gradient subtraction + density advection in one pass
+  K_DIFFUSE_TILE,         // LDS-tiled sweeps for small grids (fluid_kernels_tile.hip)
+  K_JACOBI_TILE,
+  K_JACOBI_DIV_TILE,
   K_COUNT
 };
 extern const char *const kKernelNames[K_COUNT];
@@ -71,3 +74,13 @@ bool launch_jacobi_div_tb(hipStream_t s, Geom g, int r0, int r1, int k, int cols
                           const float2 *vel, float *div_out, float *pout, void *dump);
 bool launch_diffuse_tb(hipStream_t s, Geom g, int r0, int r1, int k, int cols, int chunk,
                        float alpha, float beta, const float2 *vin, float2 *vout, void *dump);
+
+// ---- LDS-tiled sweeps for small grids (fluid_kernels_tile.hip) ---------------
+// k sweeps per launch on local rows [r0, r1); false when k is not instantiated.
+bool tile_has_k(int k, bool float2_field);
+bool launch_jacobi_tile(hipStream_t s, Geom g, int r0, int r1, int k, const float *pin, const float *div,
+                        float *pout);
+bool launch_jacobi_div_tile(hipStream_t s, Geom g, int r0, int r1, int k, const float2 *vel, float *div_out,
+                            float *pout);
+bool launch_diffuse_tile(hipStream_t s, Geom g, int r0, int r1, int k, float alpha, float beta,
+                         const float2 *vin, float2 *vout);

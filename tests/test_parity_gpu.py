@@ -241,6 +241,7 @@ def test_temporal_blocking_plans_bit_exact(pkg, hip, oracle, plan, monkeypatch):
     decompose into mixed passes, rough random data."""
     for name, v in zip(("FLUID_TB_KJ", "FLUID_TB_CJ", "FLUID_TB_KD", "FLUID_TB_CD", "FLUID_TB_WAVES"), plan):
         monkeypatch.setenv(name, str(v))
+    monkeypatch.setenv("FLUID_TILE", "0")  # the register pipeline, not the small-grid LDS tiles
     n, D, J = 600, 13, 37
     gpu, ref = pair(pkg, hip, oracle, n, diffusion_iters=D, pressure_iters=J)
     state = random_state(n, seed=21, vmax=30.0)
@@ -268,6 +269,7 @@ def test_temporal_blocking_every_phase_at_the_borders(pkg, hip, oracle, k, cols,
     monkeypatch.setenv("FLUID_TB_CJ", str(cols))
     monkeypatch.setenv("FLUID_TB_KD", str(k))
     monkeypatch.setenv("FLUID_TB_WAVES", "1")  # one chunk per strip: the pipeline runs top to bottom
+    monkeypatch.setenv("FLUID_TILE", "0")
     for n in (96, 100, 104):
         gpu, ref = pair(pkg, hip, oracle, n, diffusion_iters=3 * k, pressure_iters=3 * k)
         state = random_state(n, seed=n + k, vmax=20.0)
@@ -279,3 +281,37 @@ def test_temporal_blocking_every_phase_at_the_borders(pkg, hip, oracle, k, cols,
             a, b = read_all(gpu, pkg), read_all(ref, pkg)
             for f in ("velocity", "pressure"):
                 assert_bit_equal(a[f], b[f], f"{stage}/{f} n={n} k={k} cols={cols}")
+
+
+@pytest.mark.parametrize("k", [1, 2, 4, 5, 8, 10])
+def test_lds_tiles_bit_exact(pkg, hip, oracle, k, monkeypatch):
+    """The small-grid path (fluid_kernels_tile.hip: K sweeps on a 64 x 32 tile held in LDS) gives the
+    bits of the sweep-by-sweep oracle: grids that are not multiples of the tile, tiles cut by every
+    domain border, sweep counts that split into mixed passes, later passes starting from a
+    non-zero iterate."""
+    monkeypatch.setenv("FLUID_TILE", "1")
+    monkeypatch.setenv("FLUID_TB_KJ", str(k))
+    monkeypatch.setenv("FLUID_TB_KD", str(k))
+    for n, D, J in ((96, 2 * k + 1, 3 * k), (100, k, 2 * k + 3), (31, 3, 7), (257, 10, 40)):
+        gpu, ref = pair(pkg, hip, oracle, n, diffusion_iters=D, pressure_iters=J)
+        state = random_state(n, seed=n + k, vmax=20.0)
+        for stage in ("diffuse", "project"):
+            load_state(gpu, pkg, *state)
+            load_state(ref, pkg, *state)
+            getattr(gpu, stage)()
+            getattr(ref, stage)()
+            a, b = read_all(gpu, pkg), read_all(ref, pkg)
+            for f in ("velocity", "pressure", "divergence"):
+                assert_bit_equal(a[f], b[f], f"{stage}/{f} n={n} k={k}")
+
+
+def test_lds_tiles_whole_steps_and_zero_sweeps(pkg, hip, oracle, monkeypatch):
+    """Whole seeded steps through the tile path, including J = 0 and D = 0."""
+    monkeypatch.setenv("FLUID_TILE", "1")
+    for n, D, J in ((128, 10, 40), (200, 0, 5), (64, 3, 0)):
+        gpu, ref = pair(pkg, hip, oracle, n, diffusion_iters=D, pressure_iters=J)
+        pkg.run_seeded(gpu, 4)
+        pkg.run_seeded(ref, 4)
+        a, b = read_all(gpu, pkg), read_all(ref, pkg)
+        for f in ("velocity", "density", "pressure", "divergence"):
+            assert rel_err(a[f], b[f]) <= 1e-5, (n, f)

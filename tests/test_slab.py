@@ -71,14 +71,18 @@ def test_halo_exchange_protocol_over_gloo(world, n, D, J, A):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("flags", [0, 4], ids=["fused", "unfused"])
+@pytest.mark.parametrize("flags", [0, 4, "pipeline"], ids=["tiles", "unfused", "pipeline"])
 @pytest.mark.parametrize("count,n,D,J,A", [(2, 256, 10, 10, 1), (4, 512, 10, 40, 8), (3, 300, 3, 7, 2),
                                            (8, 1024, 10, 40, 8)])
-def test_slabs_equal_whole_domain(pkg, hip, count, n, D, J, A, flags):
+def test_slabs_equal_whole_domain(pkg, hip, count, n, D, J, A, flags, monkeypatch):
     """K slab contexts + halo pack/unpack == one whole-domain context, bit for bit, over several
     steps with seeded splats (A=1 makes the halo exactly as deep as the dependency cone, so any
-    off-by-one in a stage's row range shows)."""
+    off-by-one in a stage's row range shows).  Small slabs take the LDS-tile sweeps by default;
+    "pipeline" forces the register pipeline the large grids use."""
     import fluid_simulation_amd.slab as slab
+    if flags == "pipeline":
+        monkeypatch.setenv("FLUID_TILE", "0")
+        flags = 0
     whole = pkg.FluidSim(n, diffusion_iters=D, pressure_iters=J, flags=flags)
     group = slab.LocalSlabGroup(pkg, n, count, diffusion_iters=D, pressure_iters=J, halo_rows=A, flags=flags)
     ss_a, ss_b = pkg.SplatStream(), pkg.SplatStream()
