@@ -556,8 +556,8 @@ int fluid_init(fluid_ctx **out, const fluid_params *p) {
   c->has_hi = si.has_hi;
   // tuning knobs (defaults chosen from measurements); results do not depend on them
   // Plan by owned cells, from sweeps on MI355X (tools/tb_sweep.py, tools/small_sweep.py):
-  //   <= ~1024^2 : launch/latency bound -> LDS tiles (fluid_kernels_tile.hip), 8 / 5 sweeps per
-  //                launch: 0.156 -> 0.112 ms at 1024^2, 0.106 -> 0.069 ms at 512^2 against the
+  //   <= ~1024^2 : launch/latency bound -> LDS tiles (fluid_kernels_tile.hip), 10 / 5 sweeps per
+  //                launch: 0.156 -> 0.110 ms at 1024^2, 0.106 -> 0.070 ms at 512^2 against the
   //                register pipeline (which wins again from ~1500^2 up); FLUID_TILE=0/1 overrides
   //   ~2048^2    : 8 sweeps per launch
   //   ~4096^2 and the slabs of a 16384^2 domain on 8 GPUs: 10 sweeps per launch, and just under
@@ -567,7 +567,7 @@ int fluid_init(fluid_ctx **out, const fluid_params *p) {
   //                twice the waves (shorter chunks even out the tail of the launch)
   const long long owned = (long long)prm.n * si.rows;
   c->tile = env_int("FLUID_TILE", owned < (1ll << 21) ? 1 : 0) != 0;
-  if (c->tile) { c->tb_kj = 8; c->tb_kd = 5; }
+  if (c->tile) { c->tb_kj = 10; c->tb_kd = 5; }
   else if (owned < (1ll << 21)) { c->tb_kj = 4; c->tb_minchunk = 1; }
   else if (owned <= (1ll << 23)) { c->tb_kj = 8; c->tb_minchunk = 1; }
   else if (owned < (1ll << 26)) { c->tb_kd = 10; c->tb_waves = 3900; c->tb_minchunk = 1; }

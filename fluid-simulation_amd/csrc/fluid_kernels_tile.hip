@@ -15,32 +15,28 @@
 
 namespace {
 
-#ifndef TILE_THREADS
-#define TILE_THREADS 1024
+#ifndef TILE_TX
+#define TILE_TX 64
 #endif
-constexpr int TX = 64, TY = 32, THREADS = TILE_THREADS;
+constexpr int TX = TILE_TX, TY = 32;  // cells a workgroup stores
+constexpr int R = 2;                   // rows of a thread's run
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
 
-// Tile geometry: K halo rows above and below, HX = K rounded up to even halo columns left and
-// right, so that a tile row is a whole number of 4-float segments (16-byte LDS accesses).
+// Tile geometry: K halo rows above and below, HX = K rounded up to a multiple of four halo
+// columns left and right, so that the tile and its stored centre are whole 4-float segments
+// (16-byte LDS and global accesses).  A thread owns a run of R vertically adjacent segments.
 template <int K> struct TileGeom {
-  static constexpr int HX = (K + 1) & ~1;
+  static constexpr int HX = (K + 3) & ~3;
   static constexpr int W = TX + 2 * HX, H = TY + 2 * K, W4 = W / 4;
-  static constexpr int SEGS = (H * W4 + THREADS - 1) / THREADS;  // segments a thread owns
-  static_assert(W % 4 == 0, "tile rows are made of float4 segments");
+  static constexpr int RUNS = (H / R) * W4;
+  static constexpr int THREADS = (RUNS + 63) / 64 * 64;
+  static constexpr int PLANE = H * W + 8;  // 4 floats of padding before and after
+  static_assert(H % R == 0 && THREADS <= 1024, "tile shape");
 };
 
-// What a thread knows about one of the 4-cell row segments it owns for all K sweeps.
-struct Seg {
-  int c;       // LDS index of its first cell (ly * W + 4 * sx); -1: not a segment / tile edge row
-  int x, y;    // global coordinates of its first cell
-};
-
-// The interior rule of one plane on a segment: rm / rp = rows y-1 / y+1, ce = the segment,
-// l / r = the cells left and right of it.
 struct F4 { float v[4]; };
-__device__ __forceinline__ F4 ld4(const float *p) {
+__device__ __forceinline__ F4 ld4(const float *p) {  // 16-byte aligned (LDS, or global with n % 4 == 0)
   const float4 t = *reinterpret_cast<const float4 *>(p);
   return F4{{t.x, t.y, t.z, t.w}};
 }
@@ -50,12 +46,12 @@ __device__ __forceinline__ void st4(float *p, const F4 &f) {
 
 // pressureJacobi, kernel.cu:291-324: interior rule :313, border rules :319-322 (y rules last)
 struct JacobiRule {
-  static __device__ __forceinline__ float interior(float L, float R, float B, float T, float, float d, float, float) {
-    return ((((L + R) + B) + T) + (-1.0f) * d) * 0.25f;
+  static __device__ __forceinline__ float interior(float L, float Rt, float B, float T, float, float d, float, float) {
+    return ((((L + Rt) + B) + T) + (-1.0f) * d) * 0.25f;
   }
-  static __device__ __forceinline__ float border(float L, float R, float B, float T, float, int x, int y, int n) {
+  static __device__ __forceinline__ float border(float L, float Rt, float B, float T, float, int x, int y, int n) {
     float o = 0.0f;
-    if (x == 0) o = -R;
+    if (x == 0) o = -Rt;
     if (x == n - 1) o = -L;
     if (y == 0) o = -T;
     if (y == n - 1) o = -B;
@@ -64,167 +60,252 @@ struct JacobiRule {
 };
 // diffusion, kernel.cu:173-205: interior rule :195, the border copies through :201-203
 struct DiffuseRule {
-  static __device__ __forceinline__ float interior(float L, float R, float B, float T, float c, float, float alpha, float beta) {
-    return ((((L + R) + B) + T) + alpha * c) * beta;
+  static __device__ __forceinline__ float interior(float L, float Rt, float B, float T, float c, float, float alpha, float beta) {
+    return ((((L + Rt) + B) + T) + alpha * c) * beta;
   }
   static __device__ __forceinline__ float border(float, float, float, float, float c, int, int, int) { return c; }
 };
 
-// One sweep of one plane over the segments this thread owns: a -> b.  `aux` = per-segment
-// constant (the divergence), `edge`: the tile touches a domain border (block-uniform).
+// Where a thread's run sits.
+template <int K> struct Run {
+  int c0;      // LDS index of the run's first segment
+  int cm, cp;  // LDS index of the segment above the run / below it (clamped into the tile)
+  int x, y;    // global coordinates of the run's first cell
+  bool active;
+  __device__ __forceinline__ void locate(int x_org, int y_org) {
+    using G = TileGeom<K>;
+    const int run = threadIdx.x;
+    const int rr = run / G::W4, sx = run - rr * G::W4, ly0 = rr * R;
+    active = run < G::RUNS;
+    c0 = active ? ly0 * G::W + 4 * sx : 0;
+    // the tile's first and last row have no row above / below: any value does, they are the
+    // ring the tile edge spoils in the first sweep anyway
+    cm = ly0 > 0 ? c0 - G::W : c0;
+    cp = ly0 + R < G::H ? c0 + R * G::W : c0 + (R - 1) * G::W;
+    x = x_org + 4 * sx;
+    y = y_org + ly0;
+  }
+};
+
+// One sweep of one plane: the run's cells stay in registers (ce) from sweep to sweep; the rows
+// above and below the run and the cells left and right of it come from LDS (a), the new values
+// go to LDS (b) for the neighbours.
 template <int K, class Rule>
-__device__ __forceinline__ void plane_sweep(const float *__restrict__ a, float *__restrict__ b,
-                                            const Seg (&seg)[TileGeom<K>::SEGS], const F4 (&aux)[TileGeom<K>::SEGS],
-                                            bool edge, int n, float alpha, float beta) {
+__device__ __forceinline__ void run_sweep(const float *__restrict__ a, float *__restrict__ b, const Run<K> &rn,
+                                          F4 (&ce)[R], const F4 (&aux)[R], bool edge, int n, float alpha,
+                                          float beta) {
   using G = TileGeom<K>;
+  const F4 rm = ld4(a + rn.cm), rp = ld4(a + rn.cp);
+  float l[R], r[R];
 #pragma unroll
-  for (int j = 0; j < G::SEGS; ++j) {
-    const int c = seg[j].c;
-    if (c < 0) continue;
-    const F4 ce = ld4(a + c), rm = ld4(a + c - G::W), rp = ld4(a + c + G::W);
-    const float l = a[c - 1], r = a[c + 4];
-    F4 o;
+  for (int j = 0; j < R; ++j) {
+    l[j] = a[rn.c0 + j * G::W - 1];
+    r[j] = a[rn.c0 + j * G::W + 4];
+  }
+  F4 o[R];
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    const F4 &up = j > 0 ? ce[j - 1] : rm, &dn = j < R - 1 ? ce[j + 1] : rp;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const float L = i > 0 ? ce.v[i - 1] : l, R = i < 3 ? ce.v[i + 1] : r;
-      o.v[i] = Rule::interior(L, R, rm.v[i], rp.v[i], ce.v[i], aux[j].v[i], alpha, beta);
-    }
-    if (edge) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int x = seg[j].x + i, y = seg[j].y;
-        if (x <= 0 || x >= n - 1 || y <= 0 || y >= n - 1) {
-          const float L = i > 0 ? ce.v[i - 1] : l, R = i < 3 ? ce.v[i + 1] : r;
-          o.v[i] = Rule::border(L, R, rm.v[i], rp.v[i], ce.v[i], x, y, n);
-        }
+      const float L = i > 0 ? ce[j].v[i - 1] : l[j], Rt = i < 3 ? ce[j].v[i + 1] : r[j];
+      float v = Rule::interior(L, Rt, up.v[i], dn.v[i], ce[j].v[i], aux[j].v[i], alpha, beta);
+      if (edge) {
+        const int x = rn.x + i, y = rn.y + j;
+        if (x <= 0 || x >= n - 1 || y <= 0 || y >= n - 1)
+          v = Rule::border(L, Rt, up.v[i], dn.v[i], ce[j].v[i], x, y, n);
       }
+      o[j].v[i] = v;
     }
-    st4(b + c, o);
+  }
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    ce[j] = o[j];
+    st4(b + rn.c0 + j * G::W, o[j]);
   }
 }
 
+// Is this one of the cells the workgroup stores?  (whole segments: HX and TX are multiples of 4)
 template <int K>
-__device__ __forceinline__ void own_segments(Seg (&seg)[TileGeom<K>::SEGS], int x_org, int y_org) {
+__device__ __forceinline__ bool stored_segment(const Run<K> &rn, int j, int x_org, int y_org, int y1, int n) {
   using G = TileGeom<K>;
-#pragma unroll
-  for (int j = 0; j < G::SEGS; ++j) {
-    const int i = threadIdx.x + j * THREADS;
-    const int ly = i / G::W4, sx = i - ly * G::W4;
-    // rows 0 and H-1 have no row above / below in the tile: never computed (they are the first
-    // ring the tile edge spoils anyway)
-    seg[j].c = (i < G::H * G::W4 && ly >= 1 && ly <= G::H - 2) ? ly * G::W + 4 * sx : -1;
-    seg[j].x = x_org + 4 * sx;
-    seg[j].y = y_org + ly;
-  }
+  const int lx = rn.x - x_org, ly = rn.y + j - y_org;
+  return rn.active && lx >= G::HX && lx < G::HX + TX && ly >= K && ly < K + TY && rn.y + j < y1 && rn.x < n;
 }
 
 // K pressure sweeps.  WITH_DIV: first launch of a projection — the divergence (kernel.cu:265-289)
 // is computed from the velocity while the tile is filled (and written out for the later
 // launches and fluid_read), p^0 == 0 is a constant (resetPressure, kernel.cu:530-540).
-// Every sweep recomputes the whole tile but its edge rows; a cell at distance d from the tile
-// edge is right for the first d sweeps, the stored centre is K or more away.  Cells outside the
-// domain hold garbage that nothing reads: interior cells have all four neighbours inside the
-// domain and the border rules read inward only.
+// Every sweep recomputes the whole tile; a cell at distance d from the tile edge is right for the
+// first d sweeps, the stored centre is K or more away.  Cells outside the domain hold garbage
+// that nothing reads: interior cells have all four neighbours inside the domain and the border
+// rules read inward only.  `edge` (block-uniform): the tile touches a domain border, rows that
+// are not stored (slab), or the grid is not a multiple of four wide — element-wise clamped
+// loads, border rules, element-wise stores; everywhere else whole segments.
 template <int K, bool WITH_DIV>
-__global__ __launch_bounds__(THREADS) void k_jacobi_tile(Geom g, int r0, int r1,
-                                                         const float *__restrict__ pin,
-                                                         const float2 *__restrict__ vel,
-                                                         const float *__restrict__ div_in,
-                                                         float *__restrict__ div_out,
-                                                         float *__restrict__ pout) {
+__global__ __launch_bounds__(TileGeom<K>::THREADS) void k_jacobi_tile(Geom g, int r0, int r1,
+                                                                      const float *__restrict__ pin,
+                                                                      const float2 *__restrict__ vel,
+                                                                      const float *__restrict__ div_in,
+                                                                      float *__restrict__ div_out,
+                                                                      float *__restrict__ pout) {
   using G = TileGeom<K>;
-  constexpr int W = G::W, H = G::H;
-  __shared__ __attribute__((aligned(16))) float A[H * W + 4], B[H * W + 4], Dv[H * W];
+  __shared__ __attribute__((aligned(16))) float lds[2 * G::PLANE];
+  float *a = lds + 4, *b = lds + G::PLANE + 4;
   const int n = g.n;
   const int x_org = blockIdx.x * TX - G::HX;        // global x of tile column 0
   const int r_org = r0 + blockIdx.y * TY - K;       // local row of tile row 0
   const int y_org = g.ybase + r_org;
-  // Fill.  Rows/columns outside the stored data are read from a clamped address: they only ever
-  // feed cells beyond the dependency cone of what this tile stores.
-  for (int i = threadIdx.x; i < H * W; i += THREADS) {
-    const int ly = i / W, lx = i - ly * W;
-    const int x = clampi(x_org + lx, 0, n - 1), r = clampi(r_org + ly, 0, g.L - 1);
-    const size_t id = (size_t)r * n + x;
-    if (WITH_DIV) {
-      const int y = g.ybase + r;
-      float d = 0.0f;
-      if (x > 0 && x < n - 1 && y > 0 && y < n - 1) {
-        const size_t up = (size_t)min(r + 1, g.L - 1) * n + x, dn = (size_t)max(r - 1, 0) * n + x;
-        const float2 vL = vel[id - 1], vR = vel[id + 1], vB = vel[dn], vT = vel[up];
-        d = 0.5f * ((vR.x - vL.x) + (vT.y - vB.y));  // kernel.cu:282
+  const bool edge = x_org <= 0 || x_org + G::W >= n || y_org <= 0 || y_org + G::H >= n || r_org < 0 ||
+                    r_org + G::H > g.L || (n & 3);
+  Run<K> rn;
+  rn.locate(x_org, y_org);
+  F4 ce[R], dv[R];
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    const int rl = rn.y + j - g.ybase;  // local row
+    if (!rn.active) {  // the padding of the workgroup: no cells, no memory accesses
+      ce[j] = dv[j] = F4{{0.0f, 0.0f, 0.0f, 0.0f}};
+    } else if (WITH_DIV && !edge) {
+      // divergence of the segment from whole-segment loads: rows rl-1, rl, rl+1 of the velocity
+      // (u0 w0 u1 w1 | u2 w2 u3 w3) and the cells left and right of it
+      const float *q = reinterpret_cast<const float *>(vel + (size_t)rl * n + rn.x);
+      const size_t pitch = 2 * (size_t)n;
+      const F4 c0 = ld4(q), c1 = ld4(q + 4);
+      const F4 b0 = ld4(q - pitch), b1 = ld4(q - pitch + 4), t0 = ld4(q + pitch), t1 = ld4(q + pitch + 4);
+      const float uL = q[-2], uR = q[8];
+      const float u[6] = {uL, c0.v[0], c0.v[2], c1.v[0], c1.v[2], uR};
+      const float wB[4] = {b0.v[1], b0.v[3], b1.v[1], b1.v[3]}, wT[4] = {t0.v[1], t0.v[3], t1.v[1], t1.v[3]};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        dv[j].v[i] = 0.5f * ((u[i + 2] - u[i]) + (wT[i] - wB[i]));  // kernel.cu:282
+        ce[j].v[i] = 0.0f;
       }
-      Dv[i] = d;
-      A[i] = 0.0f;
-      // this tile's own cells of the launch range
-      if (lx >= G::HX && lx < G::HX + TX && ly >= K && ly < K + TY && r_org + ly < r1 && x_org + lx < n) div_out[id] = d;
+    } else if (WITH_DIV) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int x = clampi(rn.x + i, 0, n - 1), r = clampi(rl, 0, g.L - 1), y = g.ybase + r;
+        float d = 0.0f;
+        if (x > 0 && x < n - 1 && y > 0 && y < n - 1) {
+          const size_t id = (size_t)r * n + x;
+          const size_t up = (size_t)min(r + 1, g.L - 1) * n + x, dn = (size_t)max(r - 1, 0) * n + x;
+          const float2 vL = vel[id - 1], vR = vel[id + 1], vB = vel[dn], vT = vel[up];
+          d = 0.5f * ((vR.x - vL.x) + (vT.y - vB.y));  // kernel.cu:282
+        }
+        dv[j].v[i] = d;
+        ce[j].v[i] = 0.0f;
+      }
+    } else if (!edge) {
+      const size_t id = (size_t)rl * n + rn.x;
+      ce[j] = ld4(pin + id);
+      dv[j] = ld4(div_in + id);
     } else {
-      A[i] = pin[id];
-      Dv[i] = div_in[id];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const size_t id = (size_t)clampi(rl, 0, g.L - 1) * n + clampi(rn.x + i, 0, n - 1);
+        ce[j].v[i] = pin[id];
+        dv[j].v[i] = div_in[id];
+      }
+    }
+    if (rn.active) st4(a + rn.c0 + j * G::W, ce[j]);
+    if (WITH_DIV && stored_segment<K>(rn, j, x_org, y_org, g.ybase + r1, n)) {
+      if (!edge) {
+        st4(div_out + (size_t)rl * n + rn.x, dv[j]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (rn.x + i < n) div_out[(size_t)rl * n + rn.x + i] = dv[j].v[i];
+      }
     }
   }
-  Seg seg[G::SEGS];
-  own_segments<K>(seg, x_org, y_org);
   __syncthreads();
-  F4 dv[G::SEGS];
-#pragma unroll
-  for (int j = 0; j < G::SEGS; ++j) dv[j] = ld4(Dv + (seg[j].c < 0 ? 0 : seg[j].c));
-  const bool edge = x_org <= 0 || x_org + W >= n || y_org <= 0 || y_org + H >= n;  // block-uniform
-  float *a = A, *b = B;
 #pragma unroll 1
   for (int s = 0; s < K; ++s) {
-    plane_sweep<K, JacobiRule>(a, b, seg, dv, edge, n, 0.0f, 0.0f);
+    if (rn.active) run_sweep<K, JacobiRule>(a, b, rn, ce, dv, edge, n, 0.0f, 0.0f);
     __syncthreads();
     float *t = a; a = b; b = t;
   }
-  for (int i = threadIdx.x; i < TX * TY; i += THREADS) {
-    const int ly = K + i / TX, lx = G::HX + (i & (TX - 1));
-    const int x = x_org + lx, r = r_org + ly;
-    if (r < r1 && x < n) pout[(size_t)r * n + x] = a[ly * W + lx];
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    if (!stored_segment<K>(rn, j, x_org, y_org, g.ybase + r1, n)) continue;
+    const size_t id = (size_t)(rn.y + j - g.ybase) * n + rn.x;
+    if (!edge) {
+      st4(pout + id, ce[j]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (rn.x + i < n) pout[id + i] = ce[j].v[i];
+    }
   }
 }
 
-// K diffusion sweeps; the two velocity components are two planes in LDS.
+// K diffusion sweeps; the two velocity components are two planes.
 template <int K>
-__global__ __launch_bounds__(THREADS) void k_diffuse_tile(Geom g, int r0, int r1, float alpha, float beta,
-                                                          const float2 *__restrict__ vin,
-                                                          float2 *__restrict__ vout) {
+__global__ __launch_bounds__(TileGeom<K>::THREADS) void k_diffuse_tile(Geom g, int r0, int r1, float alpha,
+                                                                       float beta,
+                                                                       const float2 *__restrict__ vin,
+                                                                       float2 *__restrict__ vout) {
   using G = TileGeom<K>;
-  constexpr int W = G::W, H = G::H;
-  // four planes of H * W floats; dynamic because 10 sweeps need 70 KB (static LDS stops at 64 KB)
+  // four planes; dynamic because the deep tiles need more than the 64 KB static LDS limit
   extern __shared__ __attribute__((aligned(16))) float tile_lds[];
-  constexpr int PLANE = H * W + 4;
-  float *Au = tile_lds, *Aw = Au + PLANE, *Bu = Aw + PLANE, *Bw = Bu + PLANE;
+  float *au = tile_lds + 4, *aw = au + G::PLANE, *bu = aw + G::PLANE, *bw = bu + G::PLANE;
   const int n = g.n;
   const int x_org = blockIdx.x * TX - G::HX;
   const int r_org = r0 + blockIdx.y * TY - K;
   const int y_org = g.ybase + r_org;
-  for (int i = threadIdx.x; i < H * W; i += THREADS) {
-    const int ly = i / W, lx = i - ly * W;
-    const int x = clampi(x_org + lx, 0, n - 1), r = clampi(r_org + ly, 0, g.L - 1);
-    const float2 v = vin[(size_t)r * n + x];
-    Au[i] = v.x;
-    Aw[i] = v.y;
-  }
-  Seg seg[G::SEGS];
-  own_segments<K>(seg, x_org, y_org);
-  F4 none[G::SEGS];
+  const bool edge = x_org <= 0 || x_org + G::W >= n || y_org <= 0 || y_org + G::H >= n || r_org < 0 ||
+                    r_org + G::H > g.L || (n & 3);
+  Run<K> rn;
+  rn.locate(x_org, y_org);
+  F4 cu[R], cw[R], none[R];
 #pragma unroll
-  for (int j = 0; j < G::SEGS; ++j) none[j] = F4{{0.0f, 0.0f, 0.0f, 0.0f}};
+  for (int j = 0; j < R; ++j) {
+    const int rl = rn.y + j - g.ybase;
+    none[j] = F4{{0.0f, 0.0f, 0.0f, 0.0f}};
+    if (!rn.active) {
+      cu[j] = cw[j] = none[j];
+    } else if (!edge) {
+      const float *q = reinterpret_cast<const float *>(vin + (size_t)rl * n + rn.x);
+      const F4 lo = ld4(q), hi = ld4(q + 4);  // u0 w0 u1 w1 | u2 w2 u3 w3
+      cu[j] = F4{{lo.v[0], lo.v[2], hi.v[0], hi.v[2]}};
+      cw[j] = F4{{lo.v[1], lo.v[3], hi.v[1], hi.v[3]}};
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float2 v = vin[(size_t)clampi(rl, 0, g.L - 1) * n + clampi(rn.x + i, 0, n - 1)];
+        cu[j].v[i] = v.x;
+        cw[j].v[i] = v.y;
+      }
+    }
+    if (rn.active) {
+      st4(au + rn.c0 + j * G::W, cu[j]);
+      st4(aw + rn.c0 + j * G::W, cw[j]);
+    }
+  }
   __syncthreads();
-  const bool edge = x_org <= 0 || x_org + W >= n || y_org <= 0 || y_org + H >= n;
-  float *au = Au, *aw = Aw, *bu = Bu, *bw = Bw;
 #pragma unroll 1
   for (int s = 0; s < K; ++s) {
-    plane_sweep<K, DiffuseRule>(au, bu, seg, none, edge, n, alpha, beta);
-    plane_sweep<K, DiffuseRule>(aw, bw, seg, none, edge, n, alpha, beta);
+    if (rn.active) {
+      run_sweep<K, DiffuseRule>(au, bu, rn, cu, none, edge, n, alpha, beta);
+      run_sweep<K, DiffuseRule>(aw, bw, rn, cw, none, edge, n, alpha, beta);
+    }
     __syncthreads();
     float *t = au; au = bu; bu = t;
     t = aw; aw = bw; bw = t;
   }
-  for (int i = threadIdx.x; i < TX * TY; i += THREADS) {
-    const int ly = K + i / TX, lx = G::HX + (i & (TX - 1));
-    const int x = x_org + lx, r = r_org + ly;
-    if (r < r1 && x < n) vout[(size_t)r * n + x] = make_float2(au[ly * W + lx], aw[ly * W + lx]);
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    if (!stored_segment<K>(rn, j, x_org, y_org, g.ybase + r1, n)) continue;
+    const size_t id = (size_t)(rn.y + j - g.ybase) * n + rn.x;
+    if (!edge) {
+      float *q = reinterpret_cast<float *>(vout + id);
+      st4(q, F4{{cu[j].v[0], cw[j].v[0], cu[j].v[1], cw[j].v[1]}});
+      st4(q + 4, F4{{cu[j].v[2], cw[j].v[2], cu[j].v[3], cw[j].v[3]}});
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (rn.x + i < n) vout[id + i] = make_float2(cu[j].v[i], cw[j].v[i]);
+    }
   }
 }
 
@@ -232,8 +313,8 @@ inline dim3 tile_grid(Geom g, int r0, int r1) { return dim3((g.n + TX - 1) / TX,
 
 }  // namespace
 
-// Sweep counts instantiated: the LDS tile grows with K (pressure: three float planes, 52 KB at
-// K = 10; diffusion: four, 70 KB at K = 10, dynamic LDS above the 64 KB static limit).
+// Sweep counts instantiated: the LDS tile grows with K (two planes of (TX + 2 HX) x (32 + 2K)
+// floats for the pressure, four for the velocity).
 bool tile_has_k(int k, bool) {
   switch (k) {
     case 1: case 2: case 4: case 5: case 8: case 10: return true;
@@ -241,9 +322,10 @@ bool tile_has_k(int k, bool) {
   }
 }
 
-#define TILE_JACOBI_CASE(K_, DIV_)                                                                        \
-  case K_:                                                                                               \
-    k_jacobi_tile<K_, DIV_><<<tile_grid(g, r0, r1), THREADS, 0, s>>>(g, r0, r1, pin, vel, div_in, div_out, pout); \
+#define TILE_JACOBI_CASE(K_, DIV_)                                                                  \
+  case K_:                                                                                         \
+    k_jacobi_tile<K_, DIV_><<<tile_grid(g, r0, r1), TileGeom<K_>::THREADS, 0, s>>>(g, r0, r1, pin, vel, div_in, \
+                                                                                  div_out, pout);  \
     return true;
 
 bool launch_jacobi_tile(hipStream_t s, Geom g, int r0, int r1, int k, const float *pin, const float *div_in,
@@ -273,7 +355,7 @@ template <int K>
 bool diffuse_tile_launch(hipStream_t s, Geom g, int r0, int r1, float alpha, float beta, const float2 *vin,
                          float2 *vout) {
   using G = TileGeom<K>;
-  constexpr size_t bytes = 4 * (size_t)(G::H * G::W + 4) * sizeof(float);
+  constexpr size_t bytes = 4 * (size_t)G::PLANE * sizeof(float);
   static bool raised = false;  // more than 64 KB of LDS per workgroup is an opt-in, once per kernel
   if (bytes > 64 * 1024 && !raised) {
     if (hipFuncSetAttribute((const void *)k_diffuse_tile<K>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -281,7 +363,7 @@ bool diffuse_tile_launch(hipStream_t s, Geom g, int r0, int r1, float alpha, flo
       return false;
     raised = true;
   }
-  k_diffuse_tile<K><<<tile_grid(g, r0, r1), THREADS, bytes, s>>>(g, r0, r1, alpha, beta, vin, vout);
+  k_diffuse_tile<K><<<tile_grid(g, r0, r1), G::THREADS, bytes, s>>>(g, r0, r1, alpha, beta, vin, vout);
   return true;
 }
 
