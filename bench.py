@@ -79,7 +79,7 @@ def cpu_baseline(pkg, D, J, budget_s=12.0):
     }
 
 
-def roofline_from_profile(sim, steps):
+def roofline_from_profile(sim, steps, workload):
     stats = sim.profile_steps(steps)
     dom = max(stats, key=lambda s: s["total_ms"])
     avg_ms = dom["total_ms"] / dom["launches"]
@@ -93,7 +93,8 @@ def roofline_from_profile(sim, steps):
     if os.path.exists(pmc_path):
         try:
             pmc = json.load(open(pmc_path))
-            traffic = pmc.get(dom["name"], {}).get("hbm_bytes_per_launch")
+            if pmc.get("_workload") == workload:  # counters are per launch of THAT workload's kernels
+                traffic = pmc.get(dom["name"], {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
     # `achieved` prices every sweep's algorithmic bytes (contract), so a temporally blocked
@@ -136,7 +137,7 @@ def main():
     bpc = pkg.alg_bytes_per_cell(D, J)
     gcups = n * n / t_step / 1e9
     ev_ms = sim.time_steps(args.steps) / args.steps
-    roof, per_kernel = roofline_from_profile(sim, max(2, min(args.steps, 5)))
+    roof, per_kernel = roofline_from_profile(sim, max(2, min(args.steps, 5)), args.workload)
     sim.close()
 
     out = {

@@ -49,7 +49,10 @@ out["traffic_by_kernel_family"] = {
     for b, lst in traffic.items()}
 os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
 if len(sys.argv) > 3:  # also write the table bench.py reads for roofline.traffic
-    json.dump(out["traffic_by_kernel_family"], open(sys.argv[3], "w"), indent=1, sort_keys=True)
+    table = dict(out["traffic_by_kernel_family"])
+    table["_workload"] = sys.argv[4] if len(sys.argv) > 4 else "16384_J40"  # bench.py applies it to this workload only
+    table["_source"] = dst + ".json"
+    json.dump(table, open(sys.argv[3], "w"), indent=1, sort_keys=True)
 json.dump(out, open(dst + ".json", "w"), indent=1, sort_keys=True)
 with open(dst + ".txt", "w") as fh:
     tot = sum(v.get("total_us", 0) for v in out["kernels"].values())
