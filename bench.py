@@ -138,6 +138,7 @@ def main():
     gcups = n * n / t_step / 1e9
     ev_ms = sim.time_steps(args.steps) / args.steps
     roof, per_kernel = roofline_from_profile(sim, max(2, min(args.steps, 5)), args.workload)
+    diag = sim.diagnostics()   # state after the run (wavefront reductions; outside the timed region)
     sim.close()
 
     out = {
@@ -154,6 +155,7 @@ def main():
         "hip_event_ms_per_step": round(ev_ms, 5),
         "roofline": roof,
         "kernels": per_kernel,
+        "diagnostics_after_run": diag,
     }
     if not args.no_extra:
         extra = {}

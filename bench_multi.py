@@ -75,6 +75,7 @@ def run_multi(pkg, args, n, D, J, flags):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall = float(t.item())
 
+    diag = sim.diagnostics()   # slab reductions + all-reduce, after the timed region
     if rank == 0:
         t_step = wall / args.steps
         bpc = pkg.alg_bytes_per_cell(D, J)
@@ -99,6 +100,7 @@ def run_multi(pkg, args, n, D, J, flags):
             "transport": "RCCL (torch.distributed nccl)" if backend == "nccl" else backend,
             "halo_bytes_per_step_per_rank": sim.ex.bytes_moved // max(args.steps + args.warmup, 1),
             "overlap": sim.overlap, "overlap_matches_plain_exchange": overlap_ok,
+            "diagnostics_after_run": diag,
         }
         print(json.dumps(out), flush=True)
     sim.close()

@@ -8,7 +8,7 @@ gfx950 HIP kernels).  The directory name carries a hyphen, so load it with
 There is no CPU fallback: constructing a :class:`FluidSim` without the built HIP
 library or without a GPU raises.  Nothing in this package imports ``oracle/``.
 """
-from .capi import (FluidLib, FluidSim, FluidError, FluidParams, KernelStat, SlabInfo, hip_lib_path,
+from .capi import (FluidLib, FluidSim, FluidError, FluidParams, FluidDiag, KernelStat, SlabInfo, hip_lib_path,
                    FIELD_VELOCITY, FIELD_DENSITY, FIELD_PRESSURE, FIELD_DIVERGENCE,
                    FIELD_VORTICITY, FLAG_VORTICITY, FLAG_NO_GRAPH, FLAG_UNFUSED, ABI_SYMBOLS, PART_VELOCITY, PART_DENSITY,
                    PART_VELOCITY_HEAD, PART_PRESSURE_GROUP, PART_VELOCITY_TAIL,
@@ -18,7 +18,7 @@ from .replay import replay, parse_events
 from .splats import SplatStream, COLOR_PRESETS, alg_bytes_per_cell, run_seeded, DEFAULT_SEED
 
 __all__ = [
-    "FluidLib", "FluidSim", "FluidError", "FluidParams", "KernelStat", "hip_lib_path",
+    "FluidLib", "FluidSim", "FluidError", "FluidParams", "FluidDiag", "KernelStat", "hip_lib_path",
     "FIELD_VELOCITY", "FIELD_DENSITY", "FIELD_PRESSURE", "FIELD_DIVERGENCE", "FIELD_VORTICITY",
     "FLAG_VORTICITY", "FLAG_NO_GRAPH", "FLAG_UNFUSED", "ABI_SYMBOLS", "PART_VELOCITY", "PART_DENSITY",
     "PART_VELOCITY_HEAD", "PART_PRESSURE_GROUP", "PART_VELOCITY_TAIL",

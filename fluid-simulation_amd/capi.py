@@ -22,7 +22,7 @@ _FIELD_COMPONENTS = {FIELD_VELOCITY: 2, FIELD_DENSITY: 4, FIELD_PRESSURE: 1, FIE
 ABI_SYMBOLS = [
     "fluid_default_params", "fluid_init", "fluid_destroy", "fluid_reset", "fluid_add_source",
     "fluid_step", "fluid_advect_velocity", "fluid_diffuse", "fluid_vorticity", "fluid_project",
-    "fluid_advect_density", "fluid_read", "fluid_write", "fluid_sync", "fluid_geometry",
+    "fluid_advect_density", "fluid_read", "fluid_write", "fluid_sync", "fluid_diagnostics", "fluid_geometry",
     "fluid_strerror", "fluid_last_error", "fluid_time_steps", "fluid_profile_steps",
     "fluid_stream", "fluid_set_stream",
     "fluid_slab_plan", "fluid_halo_bytes", "fluid_halo_pack", "fluid_halo_unpack",
@@ -53,6 +53,20 @@ class SlabInfo(C.Structure):
 class KernelStat(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_int), ("total_ms", C.c_float),
                 ("alg_bytes", C.c_double)]
+
+
+class FluidDiag(C.Structure):
+    _fields_ = [("max_abs_u", C.c_float), ("max_abs_v", C.c_float), ("max_abs_div", C.c_float),
+                ("max_abs_p", C.c_float), ("max_jacobi_update", C.c_float),
+                ("max_abs_div_velocity", C.c_float), ("dye", C.c_double * 4)]
+
+    MAX_KEYS = ("max_abs_u", "max_abs_v", "max_abs_div", "max_abs_p", "max_jacobi_update",
+                "max_abs_div_velocity")
+
+    def as_dict(self):
+        d = {k: float(getattr(self, k)) for k in self.MAX_KEYS}
+        d["dye"] = [float(x) for x in self.dye]
+        return d
 
 
 class FluidError(RuntimeError):
@@ -108,6 +122,7 @@ class FluidLib:
             sig(s, C.c_int, P)
         sig("fluid_read", C.c_int, P, C.c_int, P, C.c_size_t)
         sig("fluid_write", C.c_int, P, C.c_int, P, C.c_size_t)
+        sig("fluid_diagnostics", C.c_int, P, C.POINTER(FluidDiag))
         sig("fluid_geometry", C.c_int, P, C.POINTER(C.c_int), C.POINTER(C.c_int),
             C.POINTER(C.c_int))
         sig("fluid_strerror", C.c_char_p, C.c_int)
@@ -267,6 +282,12 @@ class FluidSim:
 
     def sync(self):
         self._chk(self.lib.dll.fluid_sync(self._h), "fluid_sync")
+
+    def diagnostics(self) -> dict:
+        """fluid_diagnostics: maxima and dye sums over the owned rows (wavefront reductions)."""
+        d = FluidDiag()
+        self._chk(self.lib.dll.fluid_diagnostics(self._h, C.byref(d)), "fluid_diagnostics")
+        return d.as_dict()
 
     def read(self, field: int) -> np.ndarray:
         comps = _FIELD_COMPONENTS[field]

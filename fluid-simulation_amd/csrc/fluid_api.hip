@@ -50,6 +50,8 @@ struct fluid_ctx {
   int vin = 0, din = 0, pin = 0;  // inputVelocityBuffer / inputDensityBuffer / inputPressureBuffer
   int *halo_flag = nullptr;       // device word: advection left the stored rows
   void *dump = nullptr;           // one row (n * 16 B): sink for rows a TB wave must not store
+  float *diag_partial = nullptr;  // fluid_diagnostics: per-block records + the result (allocated on first use)
+  DiagResult *diag_out = nullptr;
   char *arena = nullptr;          // the seven field buffers live in one allocation (fluid_init)
   float alpha = 0.f, beta = 0.f;  // diffusion constants, kernel.cu:182-183
   hipStream_t own_stream = nullptr, stream = nullptr;
@@ -639,6 +641,7 @@ void fluid_destroy(fluid_ctx *c) {
   if (c->vort) (void)hipFree(c->vort);
   if (c->halo_flag) (void)hipFree(c->halo_flag);
   if (c->dump) (void)hipFree(c->dump);
+  if (c->diag_partial) (void)hipFree(c->diag_partial);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -729,6 +732,31 @@ int fluid_sync(fluid_ctx *c) {
   if (!c) return FLUID_E_INVALID;
   HIPCHK(c, hipSetDevice(c->prm.device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  return check_halo_flag(c);
+}
+
+int fluid_diagnostics(fluid_ctx *c, fluid_diag *out) {
+  if (!c || !out) return FLUID_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->prm.device));
+  if (!c->diag_partial) {
+    const size_t rec_bytes = (size_t)DIAG_MAX_BLOCKS * DIAG_NREC * sizeof(float);
+    HIPCHK(c, hipMalloc(&c->diag_partial, rec_bytes + sizeof(DiagResult)));
+    c->diag_out = (DiagResult *)((char *)c->diag_partial + rec_bytes);
+  }
+  launch_diagnostics(c->stream, c->g, c->own_r0, c->own_r0 + c->rows, c->vel[c->vin], c->dens[c->din],
+                     c->prs[c->pin], c->div, c->diag_partial, c->diag_out);
+  int rc = check_launch(c);
+  if (rc) return rc;
+  DiagResult r;
+  HIPCHK(c, hipMemcpyAsync(&r, c->diag_out, sizeof r, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  out->max_abs_u = r.mx[0];
+  out->max_abs_v = r.mx[1];
+  out->max_abs_div = r.mx[2];
+  out->max_abs_p = r.mx[3];
+  out->max_jacobi_update = r.mx[4];
+  out->max_abs_div_velocity = r.mx[5];
+  for (int k = 0; k < 4; ++k) out->dye[k] = r.sm[k];
   return check_halo_flag(c);
 }
 

@@ -84,3 +84,15 @@ bool launch_jacobi_div_tile(hipStream_t s, Geom g, int r0, int r1, int k, const 
                             float *pout);
 bool launch_diffuse_tile(hipStream_t s, Geom g, int r0, int r1, int k, float alpha, float beta,
                          const float2 *vin, float2 *vout);
+
+// ---- diagnostics (fluid_kernels_diag.hip) -----------------------------------
+// Maxima (absolute values) and sums over local rows [r0, r1); rows r0-1 and r1 must hold current
+// velocity and pressure where they are inside the domain.  partial: DIAG_MAX_BLOCKS * DIAG_NREC
+// floats of device scratch; out: device record, valid when the stream has drained.
+constexpr int DIAG_NMAX = 6;  // |u|, |v|, |div buffer|, |p|, Jacobi update |p' - p|, |div of the velocity|
+constexpr int DIAG_NSUM = 4;  // dye channels
+constexpr int DIAG_NREC = DIAG_NMAX + DIAG_NSUM;
+constexpr int DIAG_MAX_BLOCKS = 2048;
+struct DiagResult { float mx[DIAG_NMAX]; double sm[DIAG_NSUM]; };
+void launch_diagnostics(hipStream_t s, Geom g, int r0, int r1, const float2 *vel, const float4 *dens,
+                        const float *p, const float *div, float *partial, DiagResult *out);

@@ -219,6 +219,32 @@ class SlabSim:
     def read(self, field):
         return self.sim.read(field)
 
+    def diagnostics(self) -> dict:
+        """fluid_diagnostics of the whole domain, on every rank: each slab reduces its own rows
+        on its GPU (after a refresh of the velocity halo rows the two stencil quantities read),
+        then the ranks combine: maxima by all-reduce(MAX), dye sums by all-reduce(SUM)."""
+        import torch.distributed as dist
+        torch = self.torch
+        if not self.ex.in_flight(self.V):   # overlap mode has the next step's halos on the way already
+            self._start(self.V)
+        self._finish(self.V)
+        d = self.sim.diagnostics()
+        dev = self.ex.device if dist.get_backend(self.ex.group) == "nccl" else "cpu"
+        keys = self.pkg.FluidDiag.MAX_KEYS
+        # NaN must survive the combination: all-reduce(MAX) may drop it, so carry it as +inf
+        mx = torch.tensor([d[k] for k in keys], dtype=torch.float32, device=dev)
+        nan = torch.isnan(mx)
+        mx = torch.where(nan, torch.full_like(mx, float("inf")), mx)
+        nanf = nan.to(torch.float32)
+        sm = torch.tensor(d["dye"], dtype=torch.float64, device=dev)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=self.ex.group)
+        dist.all_reduce(nanf, op=dist.ReduceOp.MAX, group=self.ex.group)
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM, group=self.ex.group)
+        mx = torch.where(nanf > 0, torch.full_like(mx, float("nan")), mx)
+        out = {k: float(v) for k, v in zip(keys, mx.tolist())}
+        out["dye"] = [float(v) for v in sm.tolist()]
+        return out
+
     def gather(self, field):
         """Whole field on rank 0 (None elsewhere); slabs in y order."""
         import numpy as np
@@ -319,6 +345,22 @@ class LocalSlabGroup:
                 self._each(pkg.PART_VELOCITY_TAIL)
                 self._each(D)
             self._sync()
+
+    def diagnostics(self) -> dict:
+        """Whole-domain diagnostics from the slabs' own reductions (velocity halos refreshed first)."""
+        import math
+        V = self.pkg.PART_VELOCITY
+        self._sync()
+        self._pack(V)
+        self._unpack(V)
+        self.early_valid = False
+        ds = [s.diagnostics() for s in self.sims]
+        out = {}
+        for k in self.pkg.FluidDiag.MAX_KEYS:
+            vals = [d[k] for d in ds]
+            out[k] = float("nan") if any(math.isnan(v) for v in vals) else max(vals)
+        out["dye"] = [sum(d["dye"][k] for d in ds) for k in range(4)]
+        return out
 
     def read(self, field):
         import numpy as np

@@ -122,11 +122,17 @@ int main(int argc, char **argv) {
   double t_step = ms[windows / 2] / (steps > 0 ? steps : 1) * 1e-3;
   double cells = (double)prm.n * prm.n;
   double bpc = 88.0 + 16.0 * prm.diffusion_iters + 12.0 * prm.pressure_iters;
+  fluid_diag dg; /* state after the timed steps: wavefront reductions on the device */
+  CHECK(fluid_diagnostics(ctx, &dg));
   printf("{\"n\": %d, \"diffusion_iters\": %d, \"pressure_iters\": %d, \"steps\": %d, "
          "\"ms_per_step\": %.6f, \"gcups\": %.4f, \"alg_bytes_per_cell\": %.0f, "
-         "\"effective_GBps\": %.1f, \"frac_of_8TBps\": %.4f}\n",
+         "\"effective_GBps\": %.1f, \"frac_of_8TBps\": %.4f, "
+         "\"max_abs_u\": %.9g, \"max_abs_v\": %.9g, \"max_abs_div\": %.9g, \"max_abs_p\": %.9g, "
+         "\"max_jacobi_update\": %.9g, \"max_abs_div_velocity\": %.9g, \"dye\": [%.9g, %.9g, %.9g, %.9g]}\n",
          prm.n, prm.diffusion_iters, prm.pressure_iters, steps, t_step * 1e3,
-         cells / t_step / 1e9, bpc, bpc * cells / t_step / 1e9, bpc * cells / t_step / 8e12);
+         cells / t_step / 1e9, bpc, bpc * cells / t_step / 1e9, bpc * cells / t_step / 8e12,
+         dg.max_abs_u, dg.max_abs_v, dg.max_abs_div, dg.max_abs_p, dg.max_jacobi_update,
+         dg.max_abs_div_velocity, dg.dye[0], dg.dye[1], dg.dye[2], dg.dye[3]);
 
   if (dump) {
     if (dump_field(ctx, dump, "velocity", FLUID_VELOCITY, 8, prm.n) ||

@@ -147,6 +147,35 @@ FLUID_API int fluid_write(fluid_ctx *ctx, int field, const void *src, size_t src
 /* cudaDeviceSynchronize analogue for this context's stream, kernel.cu:914. */
 FLUID_API int fluid_sync(fluid_ctx *ctx);
 
+/*
+ * Diagnostics of the current state over the owned rows.  No counterpart in the reference
+ * (kernel.cu has no residual or diagnostic; its only read-back is the picture, :710-756);
+ * computed on the device by wavefront reductions in a fixed order (same state, same bits) and
+ * defined with the reference's own formulas so that each value can be checked exactly:
+ *   max_abs_u/v           max |u|, max |v| of velocityBuffer[inputVelocityBuffer]; dt * max is the
+ *                         advection reach in cells (cf. fluid_params.halo_rows)
+ *   max_abs_div           max |divergenceBuffer|: right-hand side of the last projection
+ *   max_abs_p             max |pressureBuffer[inputPressureBuffer]|
+ *   max_jacobi_update     max over interior cells of |p' - p|, p' = one more pressureJacobi sweep
+ *                         (kernel.cu:313): how far the J sweeps stopped from their fixed point
+ *   max_abs_div_velocity  max over interior cells of the divergence formula (kernel.cu:282) applied
+ *                         to the current velocity: what the projection left behind
+ *   dye[4]                sum of each density channel (fp32 per block, double across blocks)
+ * A maximum is NaN if any value it covers is.  Synchronises the stream.  Slab contexts: the two
+ * stencil quantities read one halo row of velocity on each side, so refresh the velocity halos
+ * first (fluid_halo_pack_part / fluid_halo_unpack_part with FLUID_PART_VELOCITY) — the pressure
+ * rows they need are already there; combine ranks with max / sum.
+ */
+typedef struct fluid_diag {
+  float max_abs_u, max_abs_v;
+  float max_abs_div;
+  float max_abs_p;
+  float max_jacobi_update;
+  float max_abs_div_velocity;
+  double dye[4];
+} fluid_diag;
+FLUID_API int fluid_diagnostics(fluid_ctx *ctx, fluid_diag *out);
+
 /* Geometry of this context: grid edge, first owned row, number of owned rows. */
 FLUID_API int fluid_geometry(const fluid_ctx *ctx, int *n, int *row0, int *rows);
 

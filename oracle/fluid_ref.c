@@ -473,6 +473,43 @@ int fluid_write(fluid_ctx *c, int field, const void *src, size_t src_bytes) {
 
 int fluid_sync(fluid_ctx *c) { return c ? FLUID_OK : FLUID_E_INVALID; }
 
+/* fluid_diagnostics: no counterpart in the reference; a serial statement of the definitions in
+ * include/fluid.h, with the formulas of kernel.cu:313 (one more pressureJacobi sweep) and :282
+ * (divergence) in their written order.  Checker for the HIP library's wavefront reductions. */
+static float max_nan(float a, float b) { return (b > a || b != b) ? b : a; }
+int fluid_diagnostics(fluid_ctx *c, fluid_diag *out) {
+  if (!c || !out) return FLUID_E_INVALID;
+  const int n = c->prm.n;
+  const float *v = c->vel[c->vin], *d = c->dens[c->din], *p = c->prs[c->pin], *dv = c->div;
+  float mx[6] = {0, 0, 0, 0, 0, 0};
+  double sm[4] = {0, 0, 0, 0};
+  for (int y = 0; y < n; ++y)
+    for (int x = 0; x < n; ++x) {
+      const size_t id = (size_t)y * n + x;
+      mx[0] = max_nan(mx[0], fabsf(v[2 * id]));
+      mx[1] = max_nan(mx[1], fabsf(v[2 * id + 1]));
+      mx[2] = max_nan(mx[2], fabsf(dv[id]));
+      mx[3] = max_nan(mx[3], fabsf(p[id]));
+      if (x >= 1 && x <= n - 2 && y >= 1 && y <= n - 2) {
+        const float vL = p[id - 1], vR = p[id + 1], vB = p[id - n], vT = p[id + n];
+        const float next = ((((vL + vR) + vB) + vT) + (-1.0f) * dv[id]) * 0.25f; /* kernel.cu:313 */
+        mx[4] = max_nan(mx[4], fabsf(next - p[id]));
+        const float uL = v[2 * (id - 1)], uR = v[2 * (id + 1)];
+        const float wB = v[2 * (id - n) + 1], wT = v[2 * (id + n) + 1];
+        mx[5] = max_nan(mx[5], fabsf(0.5f * ((uR - uL) + (wT - wB)))); /* kernel.cu:282 */
+      }
+      for (int k = 0; k < 4; ++k) sm[k] += (double)d[4 * id + k];
+    }
+  out->max_abs_u = mx[0];
+  out->max_abs_v = mx[1];
+  out->max_abs_div = mx[2];
+  out->max_abs_p = mx[3];
+  out->max_jacobi_update = mx[4];
+  out->max_abs_div_velocity = mx[5];
+  for (int k = 0; k < 4; ++k) out->dye[k] = sm[k];
+  return FLUID_OK;
+}
+
 int fluid_geometry(const fluid_ctx *c, int *n, int *row0, int *rows) {
   if (!c) return FLUID_E_INVALID;
   if (n) *n = c->prm.n;

@@ -30,6 +30,8 @@ def main():
         sim.step(1)
     sim.step(3)                            # several steps in one call: exchanges chained back to back
     sim.sync()
+    diag = sim.diagnostics()               # slab reductions + all-reduce; every rank gets the whole domain's
+    sim.step(1)                            # and the halos it consumed are sent again
     fields = {f: sim.gather(f) for f in (pkg.FIELD_VELOCITY, pkg.FIELD_DENSITY, pkg.FIELD_PRESSURE)}
     if rank == 0:
         whole = pkg.FluidSim(n, pressure_iters=J)
@@ -39,6 +41,12 @@ def main():
                 whole.add_source(*ss.splat())
             whole.step(1)
         whole.step(3)
+        want = whole.diagnostics()
+        for k in pkg.FluidDiag.MAX_KEYS:
+            assert np.float32(diag[k]).view(np.uint32) == np.float32(want[k]).view(np.uint32), (k, diag[k], want[k])
+        for a, b in zip(diag["dye"], want["dye"]):
+            assert abs(a - b) <= 1e-6 * max(abs(b), 1.0), (diag["dye"], want["dye"])
+        whole.step(1)
         for f, got in fields.items():
             want = whole.read(f)
             assert got.shape == want.shape

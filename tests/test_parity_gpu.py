@@ -315,3 +315,71 @@ def test_lds_tiles_whole_steps_and_zero_sweeps(pkg, hip, oracle, monkeypatch):
         a, b = read_all(gpu, pkg), read_all(ref, pkg)
         for f in ("velocity", "density", "pressure", "divergence"):
             assert rel_err(a[f], b[f]) <= 1e-5, (n, f)
+
+
+DIAG_MAX = ("max_abs_u", "max_abs_v", "max_abs_div", "max_abs_p", "max_jacobi_update", "max_abs_div_velocity")
+
+
+def assert_diag_equal(a, b, what):
+    """Maxima bit for bit (a maximum does not depend on the order of the reduction); dye sums to
+    1e-6 relative (the GPU adds fp32 per block, then double across blocks; the oracle double)."""
+    for k in DIAG_MAX:
+        assert np.float32(a[k]).view(np.uint32) == np.float32(b[k]).view(np.uint32), (what, k, a[k], b[k])
+    for x, y in zip(a["dye"], b["dye"]):
+        assert abs(x - y) <= 1e-6 * max(abs(y), 1.0), (what, "dye", a["dye"], b["dye"])
+
+
+@pytest.mark.parametrize("n,J", [(4, 3), (37, 5), (96, 10), (300, 40), (1031, 12)])
+def test_diagnostics_wavefront_reductions_match_oracle(pkg, hip, oracle, n, J):
+    """fluid_diagnostics (no reference counterpart; include/fluid.h states the definitions): the
+    GPU's DPP wave reductions against the oracle's serial loops, on a rough state before any
+    step and on the state two steps later (same bits in both libraries, see above)."""
+    gpu, ref = pair(pkg, hip, oracle, n, pressure_iters=J)
+    state = random_state(n, seed=n + J, vmax=9.0)
+    load_state(gpu, pkg, *state)
+    load_state(ref, pkg, *state)
+    assert_diag_equal(gpu.diagnostics(), ref.diagnostics(), f"n={n} loaded state")
+    gpu.step(2)
+    ref.step(2)
+    a, b = gpu.diagnostics(), ref.diagnostics()
+    assert_diag_equal(a, b, f"n={n} after two steps")
+    assert a == gpu.diagnostics(), "fixed reduction order: same state, same bits"
+    if n > 4:
+        assert a["max_abs_div_velocity"] < a["max_abs_div"], "the projection removes divergence"
+
+
+def test_diagnostics_report_nan(pkg, hip):
+    """A maximum is NaN if any value it covers is (a blown-up field must not hide)."""
+    n = 70
+    gpu = pkg.FluidSim(n, lib=hip)
+    vel, dens, prs = smooth_state(n, seed=3)
+    vel[41, 17, 1] = np.nan
+    load_state(gpu, pkg, vel, dens, prs)
+    d = gpu.diagnostics()
+    assert np.isnan(d["max_abs_v"]) and np.isnan(d["max_abs_div_velocity"])
+    assert not np.isnan(d["max_abs_u"]) and not np.isnan(d["max_abs_p"])
+
+
+def test_diagnostics_full_size_properties(pkg, hip):
+    """At a BASELINE size (4096^2, J=40), where the serial oracle is not run per call: the
+    reductions against numpy on the fields read back."""
+    n = 4096
+    gpu = pkg.FluidSim(n, lib=hip, pressure_iters=40)
+    ss = pkg.SplatStream()
+    for _ in range(3):
+        gpu.add_source(*ss.splat())
+    gpu.step(2)
+    d = gpu.diagnostics()
+    vel, dens = gpu.read(pkg.FIELD_VELOCITY), gpu.read(pkg.FIELD_DENSITY)
+    prs, div = gpu.read(pkg.FIELD_PRESSURE), gpu.read(pkg.FIELD_DIVERGENCE)
+    f32 = np.float32
+    assert f32(d["max_abs_u"]) == np.abs(vel[..., 0]).max() and f32(d["max_abs_v"]) == np.abs(vel[..., 1]).max()
+    assert f32(d["max_abs_p"]) == np.abs(prs).max() and f32(d["max_abs_div"]) == np.abs(div).max()
+    c = prs[1:-1, 1:-1]
+    nxt = ((((prs[1:-1, :-2] + prs[1:-1, 2:]) + prs[:-2, 1:-1]) + prs[2:, 1:-1]) + f32(-1.0) * div[1:-1, 1:-1]) * f32(0.25)
+    assert f32(d["max_jacobi_update"]) == np.abs(nxt - c).max()
+    dv = f32(0.5) * ((vel[1:-1, 2:, 0] - vel[1:-1, :-2, 0]) + (vel[2:, 1:-1, 1] - vel[:-2, 1:-1, 1]))
+    assert f32(d["max_abs_div_velocity"]) == np.abs(dv).max()
+    for k in range(4):
+        want = dens[..., k].sum(dtype=np.float64)
+        assert abs(d["dye"][k] - want) <= 1e-6 * max(abs(want), 1.0)

@@ -119,6 +119,15 @@ def test_slabs_with_split_tail_equal_whole_domain(pkg, hip, count, n, D, J, A, G
     for f, fid in (("velocity", pkg.FIELD_VELOCITY), ("density", pkg.FIELD_DENSITY),
                    ("pressure", pkg.FIELD_PRESSURE), ("divergence", pkg.FIELD_DIVERGENCE)):
         assert_bit_equal(group.read(fid), whole.read(fid), f"{f} count={count}")
+    # fluid_diagnostics per slab (stencils across the seams read refreshed halo rows), combined
+    dg, dw = group.diagnostics(), whole.diagnostics()
+    for k in pkg.FluidDiag.MAX_KEYS:
+        assert np.float32(dg[k]).view(np.uint32) == np.float32(dw[k]).view(np.uint32), (k, dg[k], dw[k])
+    for a, b in zip(dg["dye"], dw["dye"]):
+        assert abs(a - b) <= 1e-6 * max(abs(b), 1.0)
+    whole.step(1)
+    group.step(1)   # the halo refresh of the diagnostics must not disturb the next step
+    assert_bit_equal(group.read(pkg.FIELD_DENSITY), whole.read(pkg.FIELD_DENSITY), "density after diagnostics")
     with pytest.raises(pkg.FluidError):
         group.sims[0].step_part(pkg.PART_TAIL_DENSITY_INTERIOR)  # no edges launch pending
     group.close()
