@@ -67,6 +67,12 @@ __device__ __forceinline__ float neg_opaque(float x) {
   return r;
 }
 
+// take ? -v : o, the negation an exact sign flip (see neg_opaque)
+__device__ __forceinline__ float select_neg(float o, float v, bool take) {
+  const float nv = neg_opaque(v);
+  return take ? nv : o;
+}
+
 template <int C> struct Row { float v[C]; };
 
 template <int C>
@@ -244,8 +250,16 @@ template <int C> struct JacobiOp {
       }
       return o;
     }
-    if constexpr (TB_ASM && C == 2 && !XEDGE && !YCHK) {
+    if constexpr (TB_ASM && C == 2 && !YCHK) {
       jacobi_row2_asm(o.v[0], o.v[1], b.v[0], b.v[1], a.v[0], a.v[1], n.v[0], n.v[1], d.v[0], d.v[1]);
+      if constexpr (XEDGE) {
+        // A strip at the x border runs the same rule and overwrites its one border column per
+        // side (n even: column 0 is a lane's first column, column N-1 a lane's second).  What
+        // the lanes beyond the border compute never gets past that column.  The single-round
+        // launches (4096^2, slabs) end when their slowest wave does, and these strips were it.
+        o.v[0] = select_neg(o.v[0], b.v[1], x0 == 0);          // kernel.cu:319: -p[1,y]
+        o.v[1] = select_neg(o.v[1], b.v[0], x0 + 1 == N - 1);  // kernel.cu:320: -p[N-2,y]
+      }
       return o;
     }
     const float lft = from_left(b.v[C - 1]);
@@ -296,9 +310,14 @@ template <int C> struct DiffuseOp {
     if (YCHK && (r <= 0 || r >= N - 1)) return b;  // border copies through, kernel.cu:201-203
     R o;
     const float alpha = p.alpha, beta = p.beta;
-    if constexpr (TB_ASM && C == 2 && !XEDGE && !YCHK) {
+    if constexpr (TB_ASM && C == 2 && !YCHK) {
       diffuse_row2_asm(o.u[0], o.u[1], b.u[0], b.u[1], a.u[0], a.u[1], n.u[0], n.u[1], alpha, beta);
       diffuse_row2_asm(o.w[0], o.w[1], b.w[0], b.w[1], a.w[0], a.w[1], n.w[0], n.w[1], alpha, beta);
+      if constexpr (XEDGE) {  // border columns copy through, kernel.cu:201-203 (see JacobiOp::apply)
+        const bool lo = x0 == 0, hi = x0 + 1 == N - 1;
+        o.u[0] = lo ? b.u[0] : o.u[0]; o.w[0] = lo ? b.w[0] : o.w[0];
+        o.u[1] = hi ? b.u[1] : o.u[1]; o.w[1] = hi ? b.w[1] : o.w[1];
+      }
       return o;
     }
     const float lu = from_left(b.u[C - 1]), lw = from_left(b.w[C - 1]);
