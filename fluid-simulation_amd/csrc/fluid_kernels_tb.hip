@@ -67,10 +67,22 @@ __device__ __forceinline__ float neg_opaque(float x) {
   return r;
 }
 
-// take ? -v : o, the negation an exact sign flip (see neg_opaque)
-__device__ __forceinline__ float select_neg(float o, float v, bool take) {
-  const float nv = neg_opaque(v);
-  return take ? nv : o;
+// Lane masks of the two border columns of an x-border strip (n even: column 0 is its lane's
+// first column, column N-1 its lane's second).  Wave-uniform values, computed once per wave.
+struct XBorder { unsigned long long lo, hi; };
+__device__ __forceinline__ XBorder x_border(int x0, int N) {
+  return XBorder{__builtin_amdgcn_ballot_w64(x0 == 0), __builtin_amdgcn_ballot_w64(x0 + 1 == N - 1)};
+}
+// lanes in `mask`: -v (an exact sign flip, on the way into the select); others: o.  One instruction.
+__device__ __forceinline__ float select_neg(float o, float v, unsigned long long mask) {
+  float r;
+  asm("v_cndmask_b32_e64 %0, %1, -%2, %3" : "=v"(r) : "v"(o), "v"(v), "s"(mask));
+  return r;
+}
+__device__ __forceinline__ float select_val(float o, float v, unsigned long long mask) {
+  float r;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(o), "v"(v), "s"(mask));
+  return r;
 }
 
 template <int C> struct Row { float v[C]; };
@@ -240,7 +252,7 @@ template <int C> struct JacobiOp {
 
   template <bool XEDGE, bool YCHK>
   static __device__ __forceinline__ R apply(const R &a, const R &b, const R &n, const A &d, int r,
-                                            int x0, int N, const P &) {
+                                            int x0, int N, const P &, XBorder xb) {
     R o;
     if (YCHK && (r <= 0 || r >= N - 1)) {  // wave-uniform
 #pragma unroll
@@ -257,8 +269,8 @@ template <int C> struct JacobiOp {
         // side (n even: column 0 is a lane's first column, column N-1 a lane's second).  What
         // the lanes beyond the border compute never gets past that column.  The single-round
         // launches (4096^2, slabs) end when their slowest wave does, and these strips were it.
-        o.v[0] = select_neg(o.v[0], b.v[1], x0 == 0);          // kernel.cu:319: -p[1,y]
-        o.v[1] = select_neg(o.v[1], b.v[0], x0 + 1 == N - 1);  // kernel.cu:320: -p[N-2,y]
+        o.v[0] = select_neg(o.v[0], b.v[1], xb.lo);  // kernel.cu:319: -p[1,y]
+        o.v[1] = select_neg(o.v[1], b.v[0], xb.hi);  // kernel.cu:320: -p[N-2,y]
       }
       return o;
     }
@@ -306,7 +318,7 @@ template <int C> struct DiffuseOp {
 
   template <bool XEDGE, bool YCHK>
   static __device__ __forceinline__ R apply(const R &a, const R &b, const R &n, const A &, int r,
-                                            int x0, int N, const P &p) {
+                                            int x0, int N, const P &p, XBorder xb) {
     if (YCHK && (r <= 0 || r >= N - 1)) return b;  // border copies through, kernel.cu:201-203
     R o;
     const float alpha = p.alpha, beta = p.beta;
@@ -314,9 +326,8 @@ template <int C> struct DiffuseOp {
       diffuse_row2_asm(o.u[0], o.u[1], b.u[0], b.u[1], a.u[0], a.u[1], n.u[0], n.u[1], alpha, beta);
       diffuse_row2_asm(o.w[0], o.w[1], b.w[0], b.w[1], a.w[0], a.w[1], n.w[0], n.w[1], alpha, beta);
       if constexpr (XEDGE) {  // border columns copy through, kernel.cu:201-203 (see JacobiOp::apply)
-        const bool lo = x0 == 0, hi = x0 + 1 == N - 1;
-        o.u[0] = lo ? b.u[0] : o.u[0]; o.w[0] = lo ? b.w[0] : o.w[0];
-        o.u[1] = hi ? b.u[1] : o.u[1]; o.w[1] = hi ? b.w[1] : o.w[1];
+        o.u[0] = select_val(o.u[0], b.u[0], xb.lo); o.w[0] = select_val(o.w[0], b.w[0], xb.lo);
+        o.u[1] = select_val(o.u[1], b.u[1], xb.hi); o.w[1] = select_val(o.w[1], b.w[1], xb.hi);
       }
       return o;
     }
@@ -359,8 +370,8 @@ template <int C> struct JacobiDivOp : JacobiOp<C> {
 
   template <bool XEDGE, bool YCHK>
   static __device__ __forceinline__ R apply(const R &a, const R &b, const R &n, const A &d, int r,
-                                            int x0, int N, const P &) {
-    return JacobiOp<C>::template apply<XEDGE, YCHK>(a, b, n, d, r, x0, N, typename JacobiOp<C>::P{});
+                                            int x0, int N, const P &, XBorder xb) {
+    return JacobiOp<C>::template apply<XEDGE, YCHK>(a, b, n, d, r, x0, N, typename JacobiOp<C>::P{}, xb);
   }
 
   template <bool XEDGE> struct Feed {
@@ -438,6 +449,7 @@ template <class Op, int K, bool XEDGE> struct Pipe {
   Geom g;
   int x0, xc, ya, yb;  // xc: x0 clamped into the domain (address of this lane's loads)
   bool st_ok;
+  XBorder xb;  // meaningful in x-border strips only
 
   __device__ __forceinline__ A &hh(int j) { return h[j + 2]; }
 
@@ -481,7 +493,7 @@ template <class Op, int K, bool XEDGE> struct Pipe {
       A d = cur;  // a copy of the value (never a select between two rows' addresses)
       if (l > 0) d = hh(l + 1 - J % 3);
       R o = Op::template apply<XEDGE, YCHK>(s[l][J % 3], s[l][(J + 1) % 3], s[l][(J + 2) % 3], d,
-                                            t - l - 1, x0, g.n, p);
+                                            t - l - 1, x0, g.n, p, xb);
       if (l + 1 < K) s[l + 1][(J + 2) % 3] = o; else fin = o;
     }
     return fin;
@@ -617,10 +629,12 @@ __device__ __forceinline__ void tb_kernel_body(Geom g, int r0, int r1, int chunk
   if (xedge) {
     Pipe<Op, K, true> pipe;
     pipe.g = g; pipe.x0 = x0; pipe.xc = xc; pipe.ya = ya; pipe.yb = yb; pipe.st_ok = st_ok;
+    pipe.xb = x_border(x0, g.n);
     pipe.run(p);
   } else {
     Pipe<Op, K, false> pipe;
     pipe.g = g; pipe.x0 = x0; pipe.xc = xc; pipe.ya = ya; pipe.yb = yb; pipe.st_ok = st_ok;
+    pipe.xb = XBorder{0, 0};
     pipe.run(p);
   }
 }
