@@ -262,7 +262,7 @@ template <int C> struct JacobiOp {
       }
       return o;
     }
-    if constexpr (TB_ASM && C == 2 && !YCHK) {
+    if constexpr (TB_ASM && C == 2) {
       jacobi_row2_asm(o.v[0], o.v[1], b.v[0], b.v[1], a.v[0], a.v[1], n.v[0], n.v[1], d.v[0], d.v[1]);
       if constexpr (XEDGE) {
         // A strip at the x border runs the same rule and overwrites its one border column per
@@ -322,7 +322,7 @@ template <int C> struct DiffuseOp {
     if (YCHK && (r <= 0 || r >= N - 1)) return b;  // border copies through, kernel.cu:201-203
     R o;
     const float alpha = p.alpha, beta = p.beta;
-    if constexpr (TB_ASM && C == 2 && !YCHK) {
+    if constexpr (TB_ASM && C == 2) {
       diffuse_row2_asm(o.u[0], o.u[1], b.u[0], b.u[1], a.u[0], a.u[1], n.u[0], n.u[1], alpha, beta);
       diffuse_row2_asm(o.w[0], o.w[1], b.w[0], b.w[1], a.w[0], a.w[1], n.w[0], n.w[1], alpha, beta);
       if constexpr (XEDGE) {  // border columns copy through, kernel.cu:201-203 (see JacobiOp::apply)
