@@ -556,24 +556,29 @@ int fluid_init(fluid_ctx **out, const fluid_params *p) {
   c->jg = c->groups > 1 ? si.halo_prs - 1 : prm.pressure_iters;
   c->has_lo = si.has_lo;
   c->has_hi = si.has_hi;
-  // tuning knobs (defaults chosen from measurements); results do not depend on them
-  // Plan by owned cells, from sweeps on MI355X (tools/tb_sweep.py, tools/small_sweep.py):
-  //   <= ~1024^2 : launch/latency bound -> LDS tiles (fluid_kernels_tile.hip), 10 / 5 sweeps per
-  //                launch: 0.156 -> 0.110 ms at 1024^2, 0.106 -> 0.070 ms at 512^2 against the
-  //                register pipeline (which wins again from ~1500^2 up); FLUID_TILE=0/1 overrides
-  //   ~2048^2    : 8 sweeps per launch
-  //   ~4096^2 and the slabs of a 16384^2 domain on 8 GPUs: 10 sweeps per launch, and just under
-  //                one resident round of waves (4 per SIMD x 1024 SIMDs): a few blocks over the
-  //                round cost a second one (0.718 -> 0.696 ms at 4096^2)
-  //   >= 8192^2  : HBM round trips dominate -> 13-14 Jacobi / 10 diffusion sweeps per launch,
-  //                twice the waves (shorter chunks even out the tail of the launch)
+  // Launch plan by owned cells (sweeps per launch for the pressure / diffusion loops, target
+  // waves per launch), from sweeps on MI355X (tools/plan_sweep.py, tools/slab_time.py; DESIGN.md
+  // 5.1).  Results do not depend on it; FLUID_TILE / FLUID_TB_* override it.
+  //   < 2^21  (up to ~1448^2): launch/latency bound -> LDS tiles (fluid_kernels_tile.hip)
+  //   < 2^23  (2048^2)       : 8 / 5 sweeps, 2048 waves (0.257 -> 0.221 ms against 8192 waves)
+  //   < 2^24  (a slab of 8 of 8192^2)  : 8 / 5 sweeps, one resident round of waves
+  //   < 2^25  (4096^2, a slab of 4 of 8192^2): 10 / 10 sweeps, just under one resident round
+  //           (4 waves per SIMD x 1024 SIMDs; a few blocks over cost a second round)
+  //   < 2^26  (a slab of 8 of 16384^2) : 14 / 10 sweeps, one round at 3 waves per SIMD when the
+  //           strips alone fill it (wide grids), two rounds otherwise
+  //   <= 2^27 (8192^2, slabs of 4 or 2 of 16384^2): 14 / 10 sweeps, two rounds
+  //   above   (16384^2)      : 14 / 10 sweeps, 16384 waves (shorter chunks even out the tail)
   const long long owned = (long long)prm.n * si.rows;
   c->tile = env_int("FLUID_TILE", owned < (1ll << 21) ? 1 : 0) != 0;
+  c->tb_minchunk = 1;
   if (c->tile) { c->tb_kj = 10; c->tb_kd = 5; }
-  else if (owned < (1ll << 21)) { c->tb_kj = 4; c->tb_minchunk = 1; }
-  else if (owned <= (1ll << 23)) { c->tb_kj = 8; c->tb_minchunk = 1; }
-  else if (owned < (1ll << 26)) { c->tb_kd = 10; c->tb_waves = 3900; c->tb_minchunk = 1; }
-  else { c->tb_kd = 10; c->tb_kj = 14; c->tb_waves = 16384; c->tb_minchunk = 1; }
+  else if (owned < (1ll << 21)) { c->tb_kj = 4; }
+  else if (owned < (1ll << 23)) { c->tb_kj = 8; c->tb_kd = 5; c->tb_waves = 2048; }
+  else if (owned < (1ll << 24)) { c->tb_kj = 8; c->tb_kd = 5; c->tb_waves = 3900; }
+  else if (owned < (1ll << 25)) { c->tb_kj = 10; c->tb_kd = 10; c->tb_waves = 3900; }
+  else if (owned < (1ll << 26)) { c->tb_kj = 14; c->tb_kd = 10; c->tb_waves = prm.n >= 12288 ? 3072 : 6100; }
+  else if (owned <= (1ll << 27)) { c->tb_kj = 14; c->tb_kd = 10; c->tb_waves = 6100; }
+  else { c->tb_kj = 14; c->tb_kd = 10; c->tb_waves = 16384; }
   c->tb_kj = env_int("FLUID_TB_KJ", c->tb_kj);
   c->tb_kd = env_int("FLUID_TB_KD", c->tb_kd);
   c->tb_cj = env_int("FLUID_TB_CJ", c->tb_cj);
