@@ -30,8 +30,8 @@ def run_multi(pkg, args, n, D, J, flags):
 
     # Deep pressure loops on short slabs: the J sweeps can be cut into groups with a pressure-halo
     # exchange in between (include/fluid.h, pressure_groups).  Measured on one MI355X (tools/
-    # slab_time.py, 8192^2, J = 200, one of 8 slabs, no exchange): 1.38 ms with one group (219 halo
-    # rows), 1.31 ms with 3-5 groups — less than the three extra exposed exchanges would cost, so
+    # slab_time.py, 8192^2, J = 200, one of 8 slabs, no exchange): 1.03 ms with one group (219 halo
+    # rows), 0.95-1.01 ms with 2-5 groups — less than the extra exposed exchanges would cost, so
     # groups are used only when a slab is too short for the one-exchange halo.
     rows_min = n // world
     groups = 1
