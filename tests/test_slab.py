@@ -296,3 +296,37 @@ def test_step_parts_equal_whole_step(pkg, hip):
         assert_bit_equal(a.read(f), b.read(f), f"field {f}")
     s = pkg.FluidSim(512, slab_rank=1, slab_count=4)
     assert s.halo_bytes_part(-1, pkg.PART_VELOCITY) + s.halo_bytes_part(-1, pkg.PART_DENSITY) == s.halo_bytes(-1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,J,count", [(16384, 40, 8), (8192, 200, 8), (16384, 40, 4)])
+def test_baseline_multi_gpu_configs_at_full_size(pkg, hip, n, J, count):
+    """BASELINE configs 4 and 5 at their real sizes and launch plans (the plan table of fluid_init
+    picks different sweep counts and wave counts for a 2048-row slab than for the whole domain):
+    the slabs, stepped the way the overlapped driver does, give the bits of the whole-domain
+    context.  One GPU holds everything (whole domain + all slabs: 33 GB at 16384^2); fields are
+    compared one at a time to bound host memory."""
+    import fluid_simulation_amd.slab as slab
+    whole = pkg.FluidSim(n, pressure_iters=J)
+    group = slab.LocalSlabGroup(pkg, n, count, split_tail=True, pressure_iters=J)
+    ss_a, ss_b = pkg.SplatStream(), pkg.SplatStream()
+    for _ in range(3):
+        sx, sy, fx, fy, rgba = ss_a.splat()
+        whole.add_source(sx, sy, 30 * fx, 30 * fy, rgba)   # backtraces of several cells
+        sx, sy, fx, fy, rgba = ss_b.splat()
+        group.add_source(sx, sy, 30 * fx, 30 * fy, rgba)
+    whole.step(2)
+    group.step(2)
+    for f, fid in (("velocity", pkg.FIELD_VELOCITY), ("pressure", pkg.FIELD_PRESSURE),
+                   ("density", pkg.FIELD_DENSITY)):
+        a = group.read(fid)
+        b = whole.read(fid)
+        assert a.shape == b.shape
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"{f} differs at {n}^2 / {count} slabs"
+        del a, b
+    dg, dw = group.diagnostics(), whole.diagnostics()
+    for k in pkg.FluidDiag.MAX_KEYS:
+        assert np.float32(dg[k]).view(np.uint32) == np.float32(dw[k]).view(np.uint32), (k, dg[k], dw[k])
+    assert dw["max_abs_u"] > 0 and sum(dw["dye"]) > 0
+    group.close()
+    whole.close()
