@@ -57,6 +57,11 @@ struct JacobiRule {
     if (y == n - 1) o = -B;
     return o;
   }
+  // the same rules one side at a time (border tiles: the side is known per run, see Run)
+  static __device__ __forceinline__ float x0(float, float Rt, float) { return -Rt; }
+  static __device__ __forceinline__ float x1(float L, float, float) { return -L; }
+  static __device__ __forceinline__ float y0(float, float T, float) { return -T; }
+  static __device__ __forceinline__ float y1(float B, float, float) { return -B; }
 };
 // diffusion, kernel.cu:173-205: interior rule :195, the border copies through :201-203
 struct DiffuseRule {
@@ -64,6 +69,18 @@ struct DiffuseRule {
     return ((((L + Rt) + B) + T) + alpha * c) * beta;
   }
   static __device__ __forceinline__ float border(float, float, float, float, float c, int, int, int) { return c; }
+  static __device__ __forceinline__ float x0(float, float, float c) { return c; }
+  static __device__ __forceinline__ float x1(float, float, float c) { return c; }
+  static __device__ __forceinline__ float y0(float, float, float c) { return c; }
+  static __device__ __forceinline__ float y1(float, float, float c) { return c; }
+};
+
+// How a workgroup treats its tile (block-uniform).
+enum TileMode {
+  TILE_INSIDE = 0,  // tile inside the domain and the stored rows: whole segments, no border rule
+  TILE_BORDER = 1,  // touches a domain border or rows that are not stored, n % 4 == 0: whole segments
+                    // (a segment is inside the domain or outside it), border rules by side
+  TILE_CELLS = 2    // n % 4 != 0: element-wise clamped loads, per-cell border tests, element-wise stores
 };
 
 // Where a thread's run sits.
@@ -72,7 +89,10 @@ template <int K> struct Run {
   int cm, cp;  // LDS index of the segment above the run / below it (clamped into the tile)
   int x, y;    // global coordinates of the run's first cell
   bool active;
-  __device__ __forceinline__ void locate(int x_org, int y_org) {
+  // TILE_BORDER: the run's segment holds column 0 / column n-1 (its first / last cell: n % 4 == 0);
+  // row j of the run is row 0 / row n-1; the segment lies inside the domain in x
+  bool bx0, bx1, by0[R], by1[R], yb, in_x;
+  __device__ __forceinline__ void locate(int x_org, int y_org, int n) {
     using G = TileGeom<K>;
     const int run = threadIdx.x;
     const int rr = run / G::W4, sx = run - rr * G::W4, ly0 = rr * R;
@@ -84,6 +104,16 @@ template <int K> struct Run {
     cp = ly0 + R < G::H ? c0 + R * G::W : c0 + (R - 1) * G::W;
     x = x_org + 4 * sx;
     y = y_org + ly0;
+    bx0 = x == 0;
+    bx1 = x + 3 == n - 1;
+    in_x = x >= 0 && x < n;
+    yb = false;
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      by0[j] = y + j == 0;
+      by1[j] = y + j == n - 1;
+      yb = yb || by0[j] || by1[j];
+    }
   }
 };
 
@@ -92,7 +122,7 @@ template <int K> struct Run {
 // go to LDS (b) for the neighbours.
 template <int K, class Rule>
 __device__ __forceinline__ void run_sweep(const float *__restrict__ a, float *__restrict__ b, const Run<K> &rn,
-                                          F4 (&ce)[R], const F4 (&aux)[R], bool edge, int n, float alpha,
+                                          F4 (&ce)[R], const F4 (&aux)[R], int mode, int n, float alpha,
                                           float beta) {
   using G = TileGeom<K>;
   const F4 rm = ld4(a + rn.cm), rp = ld4(a + rn.cp);
@@ -110,12 +140,36 @@ __device__ __forceinline__ void run_sweep(const float *__restrict__ a, float *__
     for (int i = 0; i < 4; ++i) {
       const float L = i > 0 ? ce[j].v[i - 1] : l[j], Rt = i < 3 ? ce[j].v[i + 1] : r[j];
       float v = Rule::interior(L, Rt, up.v[i], dn.v[i], ce[j].v[i], aux[j].v[i], alpha, beta);
-      if (edge) {
+      if (mode == TILE_CELLS) {
         const int x = rn.x + i, y = rn.y + j;
         if (x <= 0 || x >= n - 1 || y <= 0 || y >= n - 1)
           v = Rule::border(L, Rt, up.v[i], dn.v[i], ce[j].v[i], x, y, n);
       }
       o[j].v[i] = v;
+    }
+  }
+  if (mode == TILE_BORDER) {
+    // x rules first, y rules over them (kernel.cu:319-322: four independent ifs, the last wins).
+    // Column 0 / n-1 is the first / last cell of one segment per tile row: two selects per row in
+    // every wave of a tile at an x border.  Rows 0 / n-1 are one run-row of the tile: a branch only
+    // the wave or two that hold it take.
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      o[j].v[0] = rn.bx0 ? Rule::x0(l[j], ce[j].v[1], ce[j].v[0]) : o[j].v[0];
+      o[j].v[3] = rn.bx1 ? Rule::x1(ce[j].v[2], r[j], ce[j].v[3]) : o[j].v[3];
+    }
+    if (rn.yb) {
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        const F4 &up = j > 0 ? ce[j - 1] : rm, &dn = j < R - 1 ? ce[j + 1] : rp;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float v = o[j].v[i];
+          v = rn.by0[j] ? Rule::y0(up.v[i], dn.v[i], ce[j].v[i]) : v;
+          v = rn.by1[j] ? Rule::y1(up.v[i], dn.v[i], ce[j].v[i]) : v;
+          o[j].v[i] = v;
+        }
+      }
     }
   }
 #pragma unroll
@@ -139,9 +193,9 @@ __device__ __forceinline__ bool stored_segment(const Run<K> &rn, int j, int x_or
 // Every sweep recomputes the whole tile; a cell at distance d from the tile edge is right for the
 // first d sweeps, the stored centre is K or more away.  Cells outside the domain hold garbage
 // that nothing reads: interior cells have all four neighbours inside the domain and the border
-// rules read inward only.  `edge` (block-uniform): the tile touches a domain border, rows that
-// are not stored (slab), or the grid is not a multiple of four wide — element-wise clamped
-// loads, border rules, element-wise stores; everywhere else whole segments.
+// rules read inward only.  A tile that touches a domain border or rows that are not stored
+// (slab) still moves whole segments and applies the border rules by side (TileMode); only a grid
+// that is not a multiple of four wide takes the element-wise path.
 template <int K, bool WITH_DIV>
 __global__ __launch_bounds__(TileGeom<K>::THREADS) void k_jacobi_tile(Geom g, int r0, int r1,
                                                                       const float *__restrict__ pin,
@@ -157,34 +211,46 @@ __global__ __launch_bounds__(TileGeom<K>::THREADS) void k_jacobi_tile(Geom g, in
   const int r_org = r0 + blockIdx.y * TY - K;       // local row of tile row 0
   const int y_org = g.ybase + r_org;
   const bool edge = x_org <= 0 || x_org + G::W >= n || y_org <= 0 || y_org + G::H >= n || r_org < 0 ||
-                    r_org + G::H > g.L || (n & 3);
+                    r_org + G::H > g.L;
+  const int mode = (n & 3) ? TILE_CELLS : edge ? TILE_BORDER : TILE_INSIDE;
   Run<K> rn;
-  rn.locate(x_org, y_org);
+  rn.locate(x_org, y_org, n);
   F4 ce[R], dv[R];
+  const F4 zero = F4{{0.0f, 0.0f, 0.0f, 0.0f}};
 #pragma unroll
   for (int j = 0; j < R; ++j) {
     const int rl = rn.y + j - g.ybase;  // local row
-    if (!rn.active) {  // the padding of the workgroup: no cells, no memory accesses
-      ce[j] = dv[j] = F4{{0.0f, 0.0f, 0.0f, 0.0f}};
-    } else if (WITH_DIV && !edge) {
+    // TILE_BORDER: a segment is inside the domain in x or outside it; rows are clamped into the
+    // stored rows (a row outside them holds values nothing stored depends on)
+    const int rc = clampi(rl, 0, g.L - 1);
+    const bool whole = mode == TILE_INSIDE || (mode == TILE_BORDER && rn.in_x);
+    if (!rn.active || (mode == TILE_BORDER && !rn.in_x)) {
+      // the padding of the workgroup, or a segment beyond the x border: no memory accesses
+      ce[j] = dv[j] = zero;
+    } else if (WITH_DIV && whole) {
       // divergence of the segment from whole-segment loads: rows rl-1, rl, rl+1 of the velocity
       // (u0 w0 u1 w1 | u2 w2 u3 w3) and the cells left and right of it
-      const float *q = reinterpret_cast<const float *>(vel + (size_t)rl * n + rn.x);
-      const size_t pitch = 2 * (size_t)n;
+      const int rb = mode == TILE_INSIDE ? rl - 1 : max(rc - 1, 0), rt = mode == TILE_INSIDE ? rl + 1 : min(rc + 1, g.L - 1);
+      const float *q = reinterpret_cast<const float *>(vel + (size_t)rc * n + rn.x);
+      const float *qb = reinterpret_cast<const float *>(vel + (size_t)rb * n + rn.x);
+      const float *qt = reinterpret_cast<const float *>(vel + (size_t)rt * n + rn.x);
       const F4 c0 = ld4(q), c1 = ld4(q + 4);
-      const F4 b0 = ld4(q - pitch), b1 = ld4(q - pitch + 4), t0 = ld4(q + pitch), t1 = ld4(q + pitch + 4);
-      const float uL = q[-2], uR = q[8];
+      const F4 b0 = ld4(qb), b1 = ld4(qb + 4), t0 = ld4(qt), t1 = ld4(qt + 4);
+      const float uL = rn.bx0 ? 0.0f : q[rn.bx0 ? 0 : -2], uR = rn.bx1 ? 0.0f : q[rn.bx1 ? 0 : 8];
       const float u[6] = {uL, c0.v[0], c0.v[2], c1.v[0], c1.v[2], uR};
       const float wB[4] = {b0.v[1], b0.v[3], b1.v[1], b1.v[3]}, wT[4] = {t0.v[1], t0.v[3], t1.v[1], t1.v[3]};
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        dv[j].v[i] = 0.5f * ((u[i + 2] - u[i]) + (wT[i] - wB[i]));  // kernel.cu:282
+        float d = 0.5f * ((u[i + 2] - u[i]) + (wT[i] - wB[i]));  // kernel.cu:282
+        // border cells: 0 (kernel.cu:287); the flags are all false in TILE_INSIDE
+        if ((i == 0 && rn.bx0) || (i == 3 && rn.bx1) || rn.by0[j] || rn.by1[j]) d = 0.0f;
+        dv[j].v[i] = d;
         ce[j].v[i] = 0.0f;
       }
     } else if (WITH_DIV) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int x = clampi(rn.x + i, 0, n - 1), r = clampi(rl, 0, g.L - 1), y = g.ybase + r;
+        const int x = clampi(rn.x + i, 0, n - 1), r = rc, y = g.ybase + r;
         float d = 0.0f;
         if (x > 0 && x < n - 1 && y > 0 && y < n - 1) {
           const size_t id = (size_t)r * n + x;
@@ -195,21 +261,21 @@ __global__ __launch_bounds__(TileGeom<K>::THREADS) void k_jacobi_tile(Geom g, in
         dv[j].v[i] = d;
         ce[j].v[i] = 0.0f;
       }
-    } else if (!edge) {
-      const size_t id = (size_t)rl * n + rn.x;
+    } else if (whole) {
+      const size_t id = (size_t)rc * n + rn.x;
       ce[j] = ld4(pin + id);
       dv[j] = ld4(div_in + id);
     } else {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const size_t id = (size_t)clampi(rl, 0, g.L - 1) * n + clampi(rn.x + i, 0, n - 1);
+        const size_t id = (size_t)rc * n + clampi(rn.x + i, 0, n - 1);
         ce[j].v[i] = pin[id];
         dv[j].v[i] = div_in[id];
       }
     }
     if (rn.active) st4(a + rn.c0 + j * G::W, ce[j]);
     if (WITH_DIV && stored_segment<K>(rn, j, x_org, y_org, g.ybase + r1, n)) {
-      if (!edge) {
+      if (mode != TILE_CELLS) {
         st4(div_out + (size_t)rl * n + rn.x, dv[j]);
       } else {
 #pragma unroll
@@ -221,7 +287,7 @@ __global__ __launch_bounds__(TileGeom<K>::THREADS) void k_jacobi_tile(Geom g, in
   __syncthreads();
 #pragma unroll 1
   for (int s = 0; s < K; ++s) {
-    if (rn.active) run_sweep<K, JacobiRule>(a, b, rn, ce, dv, edge, n, 0.0f, 0.0f);
+    if (rn.active) run_sweep<K, JacobiRule>(a, b, rn, ce, dv, mode, n, 0.0f, 0.0f);
     __syncthreads();
     float *t = a; a = b; b = t;
   }
@@ -229,7 +295,7 @@ __global__ __launch_bounds__(TileGeom<K>::THREADS) void k_jacobi_tile(Geom g, in
   for (int j = 0; j < R; ++j) {
     if (!stored_segment<K>(rn, j, x_org, y_org, g.ybase + r1, n)) continue;
     const size_t id = (size_t)(rn.y + j - g.ybase) * n + rn.x;
-    if (!edge) {
+    if (mode != TILE_CELLS) {
       st4(pout + id, ce[j]);
     } else {
 #pragma unroll
@@ -254,25 +320,27 @@ __global__ __launch_bounds__(TileGeom<K>::THREADS) void k_diffuse_tile(Geom g, i
   const int r_org = r0 + blockIdx.y * TY - K;
   const int y_org = g.ybase + r_org;
   const bool edge = x_org <= 0 || x_org + G::W >= n || y_org <= 0 || y_org + G::H >= n || r_org < 0 ||
-                    r_org + G::H > g.L || (n & 3);
+                    r_org + G::H > g.L;
+  const int mode = (n & 3) ? TILE_CELLS : edge ? TILE_BORDER : TILE_INSIDE;
   Run<K> rn;
-  rn.locate(x_org, y_org);
+  rn.locate(x_org, y_org, n);
   F4 cu[R], cw[R], none[R];
 #pragma unroll
   for (int j = 0; j < R; ++j) {
     const int rl = rn.y + j - g.ybase;
+    const int rc = clampi(rl, 0, g.L - 1);
     none[j] = F4{{0.0f, 0.0f, 0.0f, 0.0f}};
-    if (!rn.active) {
+    if (!rn.active || (mode == TILE_BORDER && !rn.in_x)) {
       cu[j] = cw[j] = none[j];
-    } else if (!edge) {
-      const float *q = reinterpret_cast<const float *>(vin + (size_t)rl * n + rn.x);
+    } else if (mode != TILE_CELLS) {
+      const float *q = reinterpret_cast<const float *>(vin + (size_t)rc * n + rn.x);
       const F4 lo = ld4(q), hi = ld4(q + 4);  // u0 w0 u1 w1 | u2 w2 u3 w3
       cu[j] = F4{{lo.v[0], lo.v[2], hi.v[0], hi.v[2]}};
       cw[j] = F4{{lo.v[1], lo.v[3], hi.v[1], hi.v[3]}};
     } else {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const float2 v = vin[(size_t)clampi(rl, 0, g.L - 1) * n + clampi(rn.x + i, 0, n - 1)];
+        const float2 v = vin[(size_t)rc * n + clampi(rn.x + i, 0, n - 1)];
         cu[j].v[i] = v.x;
         cw[j].v[i] = v.y;
       }
@@ -286,8 +354,8 @@ __global__ __launch_bounds__(TileGeom<K>::THREADS) void k_diffuse_tile(Geom g, i
 #pragma unroll 1
   for (int s = 0; s < K; ++s) {
     if (rn.active) {
-      run_sweep<K, DiffuseRule>(au, bu, rn, cu, none, edge, n, alpha, beta);
-      run_sweep<K, DiffuseRule>(aw, bw, rn, cw, none, edge, n, alpha, beta);
+      run_sweep<K, DiffuseRule>(au, bu, rn, cu, none, mode, n, alpha, beta);
+      run_sweep<K, DiffuseRule>(aw, bw, rn, cw, none, mode, n, alpha, beta);
     }
     __syncthreads();
     float *t = au; au = bu; bu = t;
@@ -297,7 +365,7 @@ __global__ __launch_bounds__(TileGeom<K>::THREADS) void k_diffuse_tile(Geom g, i
   for (int j = 0; j < R; ++j) {
     if (!stored_segment<K>(rn, j, x_org, y_org, g.ybase + r1, n)) continue;
     const size_t id = (size_t)(rn.y + j - g.ybase) * n + rn.x;
-    if (!edge) {
+    if (mode != TILE_CELLS) {
       float *q = reinterpret_cast<float *>(vout + id);
       st4(q, F4{{cu[j].v[0], cw[j].v[0], cu[j].v[1], cw[j].v[1]}});
       st4(q + 4, F4{{cu[j].v[2], cw[j].v[2], cu[j].v[3], cw[j].v[3]}});
