@@ -1,0 +1,102 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep on the GPU (not part of pytest: minutes, not seconds).
+  A. fused path vs the CPU oracle, small random grids, random D / J, bit for bit
+  B. fused vs straight (FLUID_FLAG_UNFUSED) path, random grids up to 3000^2 incl. odd sizes
+  C. slab groups (random count, split tail, pressure groups) vs the whole domain
+Usage: python tools/fuzz_parity.py [seed] [cases_a cases_b cases_c]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import fluid_amd_loader  # noqa: E402
+from util import random_state, smooth_state, load_state  # noqa: E402
+
+pkg = fluid_amd_loader.load()
+import fluid_simulation_amd.slab as slab  # noqa: E402
+
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+na, nb, nc = (int(v) for v in sys.argv[2:5]) if len(sys.argv) > 4 else (120, 60, 60)
+rng = np.random.default_rng(seed)
+oracle = pkg.FluidLib(os.path.join(ROOT, "oracle", "liboracle_fluid.so"))
+F = (("velocity", pkg.FIELD_VELOCITY), ("density", pkg.FIELD_DENSITY), ("pressure", pkg.FIELD_PRESSURE),
+     ("divergence", pkg.FIELD_DIVERGENCE))
+bad = 0
+
+
+def same(a, b):
+    return a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def compare(tag, x, y):
+    global bad
+    for name, fid in F:
+        if not same(x.read(fid), y.read(fid)):
+            bad += 1
+            print("MISMATCH", tag, name, flush=True)
+            return False
+    return True
+
+
+for i in range(na):
+    n = int(rng.integers(4, 420))
+    D, J = int(rng.integers(0, 13)), int(rng.integers(0, 46))
+    st = (random_state(n, seed=i, vmax=float(rng.uniform(1, 60))) if rng.random() < 0.5 else smooth_state(n, seed=i))
+    g = pkg.FluidSim(n, diffusion_iters=D, pressure_iters=J)
+    r = pkg.FluidSim(n, lib=oracle, diffusion_iters=D, pressure_iters=J)
+    load_state(g, pkg, *st)
+    load_state(r, pkg, *st)
+    steps = int(rng.integers(1, 4))
+    g.step(steps)
+    r.step(steps)
+    compare(f"A n={n} D={D} J={J} steps={steps}", g, r)
+    g.close(); r.close()
+print(f"A done ({na} cases), mismatches so far {bad}", flush=True)
+
+for i in range(nb):
+    n = int(rng.integers(300, 3000))
+    if rng.random() < 0.6:
+        n = n // 4 * 4
+    D, J = int(rng.integers(0, 13)), int(rng.integers(0, 46))
+    st = smooth_state(n, seed=1000 + i)
+    a = pkg.FluidSim(n, diffusion_iters=D, pressure_iters=J)
+    b = pkg.FluidSim(n, diffusion_iters=D, pressure_iters=J, flags=pkg.FLAG_UNFUSED)
+    load_state(a, pkg, *st)
+    load_state(b, pkg, *st)
+    a.step(2)
+    b.step(2)
+    compare(f"B n={n} D={D} J={J}", a, b)
+    a.close(); b.close()
+print(f"B done ({nb} cases), mismatches so far {bad}", flush=True)
+
+for i in range(nc):
+    count = int(rng.integers(2, 7))
+    D, J, A = int(rng.integers(0, 11)), int(rng.integers(1, 41)), int(rng.integers(1, 9))
+    G = int(rng.integers(0, 4))
+    need = (J + max(G, 1) - 1) // max(G, 1) + 1 + D + A
+    n = int(rng.integers(max(count * (need + 4), 64), 2200)) // 2 * 2
+    split = bool(rng.random() < 0.6)
+    try:
+        grp = slab.LocalSlabGroup(pkg, n, count, split_tail=split, diffusion_iters=D, pressure_iters=J, halo_rows=A,
+                                  pressure_groups=G)
+    except pkg.FluidError as e:
+        print("skip", n, count, D, J, A, G, e)
+        continue
+    whole = pkg.FluidSim(n, diffusion_iters=D, pressure_iters=J)
+    ss_a, ss_b = pkg.SplatStream(), pkg.SplatStream()
+    for s in range(3):
+        whole.add_source(*ss_a.splat())
+        grp.add_source(*ss_b.splat())
+        whole.step(1)
+        grp.step(1)
+    for name, fid in F[:3]:
+        if not same(grp.read(fid), whole.read(fid)):
+            bad += 1
+            print("MISMATCH C", n, count, D, J, A, G, split, name, flush=True)
+            break
+    grp.close(); whole.close()
+print(f"C done ({nc} cases), mismatches {bad}", flush=True)
+sys.exit(1 if bad else 0)
