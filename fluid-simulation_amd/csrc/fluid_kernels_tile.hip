@@ -210,8 +210,12 @@ __global__ __launch_bounds__(TileGeom<K>::THREADS) void k_jacobi_tile(Geom g, in
   const int x_org = blockIdx.x * TX - G::HX;        // global x of tile column 0
   const int r_org = r0 + blockIdx.y * TY - K;       // local row of tile row 0
   const int y_org = g.ybase + r_org;
-  const bool edge = x_org <= 0 || x_org + G::W >= n || y_org <= 0 || y_org + G::H >= n || r_org < 0 ||
-                    r_org + G::H > g.L;
+  // WITH_DIV reads the velocity one row above and below every tile row: the tile must then lie a
+  // row inside the stored rows to take the unclamped path (a slab's tile can start at its local
+  // row 0 without touching the domain border)
+  constexpr int RM = WITH_DIV ? 1 : 0;
+  const bool edge = x_org <= 0 || x_org + G::W >= n || y_org <= 0 || y_org + G::H >= n || r_org < RM ||
+                    r_org + G::H > g.L - RM;
   const int mode = (n & 3) ? TILE_CELLS : edge ? TILE_BORDER : TILE_INSIDE;
   Run<K> rn;
   rn.locate(x_org, y_org, n);

@@ -197,7 +197,10 @@ def test_slab_plan_with_pressure_groups(pkg, hip):
 @pytest.mark.gpu
 @pytest.mark.parametrize("flags", [0, 4], ids=["fused", "unfused"])
 @pytest.mark.parametrize("count,n,D,J,A,G", [(2, 256, 10, 10, 1, 2), (4, 512, 10, 40, 8, 4), (3, 300, 3, 7, 2, 3),
-                                             (4, 1024, 10, 200, 8, 5), (2, 128, 2, 9, 1, 9)])
+                                             (4, 1024, 10, 200, 8, 5), (2, 128, 2, 9, 1, 9),
+                                             # found by tools/fuzz_parity.py: the divergence tile of the
+                                             # second slab starts at its local row 0 (read row -1)
+                                             (2, 1136, 4, 27, 5, 2)])
 def test_slabs_with_pressure_groups_equal_whole_domain(pkg, hip, count, n, D, J, A, G, flags):
     """The grouped pressure loop (head, pressure-halo exchange + group, ..., tail) gives the bits of
     the whole-domain run: uneven last groups, one sweep per group, temporal-blocking passes that
