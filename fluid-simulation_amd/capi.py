@@ -122,7 +122,7 @@ class FluidLib:
             sig(s, C.c_int, P)
         sig("fluid_read", C.c_int, P, C.c_int, P, C.c_size_t)
         sig("fluid_write", C.c_int, P, C.c_int, P, C.c_size_t)
-        sig("fluid_diagnostics", C.c_int, P, C.POINTER(FluidDiag))
+        sig("fluid_diagnostics", C.c_int, P, C.POINTER(FluidDiag), required=False)
         sig("fluid_geometry", C.c_int, P, C.POINTER(C.c_int), C.POINTER(C.c_int),
             C.POINTER(C.c_int))
         sig("fluid_strerror", C.c_char_p, C.c_int)

@@ -360,7 +360,18 @@ template <int C> struct JacobiDivOp : JacobiOp<C> {
   using A = Row<C>;
   using Elem = float;
   struct P { const float2 *vel; float *div_out; float *out; float *dump; int n; };
-  static __device__ __forceinline__ R load(const P &, size_t) { return zero_row<C>(); }
+  // p^0 == 0, as a value the optimiser cannot see through.  With a literal zero row the first sweep
+  // of the columns whose neighbours are all in this lane (four columns per lane: the middle two)
+  // folds to (0 - d) * 0.25, and the AMDGPU instruction selector turns fsub(+0, d) feeding a
+  // multiply into a negate modifier: -0 where the reference's sum gives +0 (d == +0 away from any
+  // splat).  Found by tools/fuzz_parity.py on the non-default four-column plans; bit-exactness
+  // includes the sign of zero.
+  static __device__ __forceinline__ R load(const P &, size_t) {
+    R r;
+#pragma unroll
+    for (int c = 0; c < C; ++c) asm("v_mov_b32 %0, 0" : "=v"(r.v[c]));
+    return r;
+  }
   static __device__ __forceinline__ Elem *out_ptr(const P &p, bool real, size_t off, size_t doff) {
     return real ? p.out + off : p.dump + doff;
   }
@@ -469,7 +480,12 @@ template <class Op, int K, bool XEDGE> struct Pipe {
 #pragma unroll
     for (int l = 0; l < K; ++l) {
 #pragma unroll
-      for (int j = 0; j < 3; ++j) s[l][j] = Op::zero();
+      for (int j = 0; j < 3; ++j) {
+        // a level 0 that is not read from memory (p^0 == 0) stays in its slots for the whole run:
+        // Op::load gives it as values the optimiser cannot fold (JacobiDivOp::load)
+        if (l == 0 && !Op::kLoadsField) s[l][j] = Op::load(p, 0);
+        else s[l][j] = Op::zero();
+      }
     }
 #pragma unroll
     for (int j = 0; j < K + 3; ++j) h[j] = Op::zero_aux();

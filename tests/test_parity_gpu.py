@@ -255,6 +255,25 @@ def test_temporal_blocking_plans_bit_exact(pkg, hip, oracle, plan, monkeypatch):
             assert_bit_equal(a[f], b[f], f"{stage}/{f} plan={plan}")
 
 
+@pytest.mark.parametrize("n,D,J,kj", [(1080, 3, 2, 10), (1572, 1, 4, 10), (1264, 2, 1, 5)])
+def test_four_column_plans_keep_the_sign_of_zero(pkg, hip, oracle, n, D, J, kj, monkeypatch):
+    """Found by tools/fuzz_parity.py: with four columns per lane and p^0 == 0 as a literal, the first
+    sweep of the in-lane columns compiled to (-d) * 0.25, i.e. -0 instead of +0 wherever the field is
+    still zero — invisible on random data, visible on a splat.  Bit parity includes the sign of zero."""
+    for name, v in (("FLUID_TB_KJ", kj), ("FLUID_TB_CJ", 4), ("FLUID_TB_KD", 2), ("FLUID_TB_CD", 4),
+                    ("FLUID_TB_WAVES", 64), ("FLUID_TILE", 0)):
+        monkeypatch.setenv(name, str(v))
+    gpu, ref = pair(pkg, hip, oracle, n, diffusion_iters=D, pressure_iters=J)
+    ss = pkg.SplatStream()
+    ref.add_source(*ss.splat())
+    load_state(gpu, pkg, ref.read(pkg.FIELD_VELOCITY), ref.read(pkg.FIELD_DENSITY), ref.read(pkg.FIELD_PRESSURE))
+    gpu.step(1)
+    ref.step(1)
+    a, b = read_all(gpu, pkg), read_all(ref, pkg)
+    for f in FIELDS:
+        assert_bit_equal(a[f], b[f], f"{f} n={n} J={J}")
+
+
 @pytest.mark.parametrize("cols", [2, 4])
 @pytest.mark.parametrize("k", [1, 2, 4, 5, 8, 10, 13, 14])
 def test_temporal_blocking_every_phase_at_the_borders(pkg, hip, oracle, k, cols, monkeypatch):

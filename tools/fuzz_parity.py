@@ -3,7 +3,8 @@
   A. fused path vs the CPU oracle, small random grids, random D / J, bit for bit
   B. fused vs straight (FLUID_FLAG_UNFUSED) path, random grids up to 3000^2 incl. odd sizes
   C. slab groups (random count, split tail, pressure groups) vs the whole domain
-Usage: python tools/fuzz_parity.py [seed] [cases_a cases_b cases_c]"""
+  D. random launch plans (FLUID_TB_* / FLUID_TILE), whole domain and slabs, fused vs straight path
+Usage: python tools/fuzz_parity.py [seed] [cases_a cases_b cases_c cases_d]"""
 import os
 import sys
 
@@ -20,6 +21,7 @@ import fluid_simulation_amd.slab as slab  # noqa: E402
 
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 na, nb, nc = (int(v) for v in sys.argv[2:5]) if len(sys.argv) > 4 else (120, 60, 60)
+nd = int(sys.argv[5]) if len(sys.argv) > 5 else 60
 rng = np.random.default_rng(seed)
 oracle = pkg.FluidLib(os.path.join(ROOT, "oracle", "liboracle_fluid.so"))
 F = (("velocity", pkg.FIELD_VELOCITY), ("density", pkg.FIELD_DENSITY), ("pressure", pkg.FIELD_PRESSURE),
@@ -77,7 +79,7 @@ for i in range(nc):
     D, J, A = int(rng.integers(0, 11)), int(rng.integers(1, 41)), int(rng.integers(1, 9))
     G = int(rng.integers(0, 4))
     need = (J + max(G, 1) - 1) // max(G, 1) + 1 + D + A
-    n = int(rng.integers(max(count * (need + 4), 64), 2200)) // 2 * 2
+    n = int(rng.integers(max(count * (need + 4), 64), 2200 if rng.random() < 0.7 else 4400)) // 2 * 2
     split = bool(rng.random() < 0.6)
     try:
         grp = slab.LocalSlabGroup(pkg, n, count, split_tail=split, diffusion_iters=D, pressure_iters=J, halo_rows=A,
@@ -99,4 +101,47 @@ for i in range(nc):
             break
     grp.close(); whole.close()
 print(f"C done ({nc} cases), mismatches {bad}", flush=True)
+
+PLAN_ENV = ("FLUID_TB_KJ", "FLUID_TB_KD", "FLUID_TB_CJ", "FLUID_TB_CD", "FLUID_TB_WAVES", "FLUID_TB_MINCHUNK", "FLUID_TILE")
+for i in range(nd):
+    for k in PLAN_ENV:
+        os.environ.pop(k, None)
+    env = {"FLUID_TB_KJ": int(rng.choice([1, 2, 4, 5, 8, 10, 13, 14])), "FLUID_TB_KD": int(rng.choice([1, 2, 4, 5, 8, 10])),
+           "FLUID_TB_CJ": int(rng.choice([2, 4])), "FLUID_TB_CD": int(rng.choice([2, 4])),
+           "FLUID_TB_WAVES": int(rng.choice([1, 7, 64, 500, 2048, 3900, 20000])),
+           "FLUID_TB_MINCHUNK": int(rng.integers(1, 5)), "FLUID_TILE": int(rng.integers(0, 2))}
+    D, J = int(rng.integers(0, 13)), int(rng.integers(0, 46))
+    count = int(rng.integers(1, 5))
+    A = int(rng.integers(1, 9))
+    n = int(rng.integers(max(count * (J + 1 + D + A + 4), 16), 1800)) // 2 * 2
+    if rng.random() < 0.5:
+        n = n // 4 * 4
+    ref = pkg.FluidSim(n, diffusion_iters=D, pressure_iters=J, flags=pkg.FLAG_UNFUSED)   # plan-independent
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        if count == 1:
+            tst = pkg.FluidSim(n, diffusion_iters=D, pressure_iters=J)
+        else:
+            tst = slab.LocalSlabGroup(pkg, n, count, split_tail=bool(rng.random() < 0.5), diffusion_iters=D,
+                                      pressure_iters=J, halo_rows=A)
+    except pkg.FluidError as e:
+        print("skip", n, count, D, J, A, env, e)
+        ref.close()
+        continue
+    finally:
+        for k in PLAN_ENV:
+            os.environ.pop(k, None)
+    ss_a, ss_b = pkg.SplatStream(), pkg.SplatStream()
+    for s_ in range(2):
+        ref.add_source(*ss_a.splat())
+        tst.add_source(*ss_b.splat())
+        ref.step(1)
+        tst.step(1)
+    for name, fid in F[:3]:
+        if not same(tst.read(fid), ref.read(fid)):
+            bad += 1
+            print("MISMATCH D", n, count, D, J, A, env, name, flush=True)
+            break
+    tst.close(); ref.close()
+print(f"D done ({nd} cases), mismatches {bad}", flush=True)
 sys.exit(1 if bad else 0)
