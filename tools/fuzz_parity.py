@@ -81,9 +81,10 @@ for i in range(nc):
     need = (J + max(G, 1) - 1) // max(G, 1) + 1 + D + A
     n = int(rng.integers(max(count * (need + 4), 64), 2200 if rng.random() < 0.7 else 4400)) // 2 * 2
     split = bool(rng.random() < 0.6)
+    fl = pkg.FLAG_UNFUSED if rng.random() < 0.2 else 0
     try:
-        grp = slab.LocalSlabGroup(pkg, n, count, split_tail=split, diffusion_iters=D, pressure_iters=J, halo_rows=A,
-                                  pressure_groups=G)
+        grp = slab.LocalSlabGroup(pkg, n, count, split_tail=split and not fl, diffusion_iters=D, pressure_iters=J,
+                                  halo_rows=A, pressure_groups=G, flags=fl)
     except pkg.FluidError as e:
         print("skip", n, count, D, J, A, G, e)
         continue
