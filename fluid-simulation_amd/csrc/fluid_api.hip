@@ -59,6 +59,7 @@ struct fluid_ctx {
   // temporal-blocking plan (fused path): sweeps per launch, columns per lane, target waves
   int tb_kj = 10, tb_kd = 5, tb_cj = 2, tb_cd = 2, tb_waves = 8192, tb_minchunk = 4;
   bool tile = false;  // small grids: LDS-tiled sweeps (fluid_kernels_tile.hip) instead of the register pipeline
+  bool nt_stores = false;  // grids far beyond the caches: non-temporal stores in the two streaming kernels
   bool prof = false;
   std::vector<hipEvent_t> ev_pool;
   size_t ev_used = 0;
@@ -148,7 +149,7 @@ void enq_advect_velocity(fluid_ctx *c, int out_m) {
   ProfScope p(c, K_ADVECT_VEL, 16.0 * cells);
   const Range r = widened(c, out_m);
   launch_advect_vel(c->stream, c->g, r.r0, r.r1, 0, c->g.L, c->prm.dt, c->vel[c->vin],
-                    c->vel[c->vin ^ 1], c->halo_flag);
+                    c->vel[c->vin ^ 1], c->halo_flag, c->nt_stores);
   c->vin ^= 1;
 }
 
@@ -336,7 +337,7 @@ void enq_gradient(fluid_ctx *c, bool with_density) {
     const Range valid = c->slab ? widened(c, c->halo_dens) : Range{0, c->g.L};
     launch_project_advect_dens(c->stream, c->g, r.r0, r.r1, valid.r0, valid.r1, c->prm.dt,
                                c->vel[c->vin], c->prs[c->pin], c->vel[c->vin ^ 1], c->dens[c->din],
-                               c->dens[c->din ^ 1], c->halo_flag);
+                               c->dens[c->din ^ 1], c->halo_flag, c->nt_stores);
     c->vin ^= 1;
     c->din ^= 1;
     return;
@@ -365,7 +366,7 @@ void enq_gradient_density_rows(fluid_ctx *c, bool edges) {
     ProfScope p(c, K_PROJECT_ADVECT_DENS, 60.0 * (double)c->g.n * (r.r1 - r.r0));
     launch_project_advect_dens(c->stream, c->g, r.r0, r.r1, valid.r0, valid.r1, c->prm.dt,
                                c->vel[vi], c->prs[c->pin], c->vel[vi ^ 1], c->dens[di],
-                               c->dens[di ^ 1], c->halo_flag);
+                               c->dens[di ^ 1], c->halo_flag, c->nt_stores && !edges);  // edge rows are packed next
   }
   if (edges) {
     c->vin ^= 1;
@@ -579,6 +580,7 @@ int fluid_init(fluid_ctx **out, const fluid_params *p) {
   else if (owned < (1ll << 26)) { c->tb_kj = 14; c->tb_kd = 10; c->tb_waves = prm.n >= 12288 ? 3072 : 6100; }
   else if (owned <= (1ll << 27)) { c->tb_kj = 14; c->tb_kd = 10; c->tb_waves = 6100; }
   else { c->tb_kj = 14; c->tb_kd = 10; c->tb_waves = 16384; }
+  c->nt_stores = env_int("FLUID_NT", (long long)prm.n * si.store_rows >= (1ll << 25) ? 1 : 0) != 0;
   c->tb_kj = env_int("FLUID_TB_KJ", c->tb_kj);
   c->tb_kd = env_int("FLUID_TB_KD", c->tb_kd);
   c->tb_cj = env_int("FLUID_TB_CJ", c->tb_cj);

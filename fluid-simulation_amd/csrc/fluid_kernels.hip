@@ -28,6 +28,30 @@ constexpr int BY = 4;
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
 __device__ __forceinline__ float2 neg(float2 v) { return make_float2(-v.x, -v.y); }
+
+// Stores of a field that is written once and next read a whole pass later.  On a grid far beyond
+// the caches (16384^2: 2-4 GB per field against 4 MB of L2 per XCD and 256 MB of MALL) a
+// non-temporal store keeps those lines from evicting the p / velocity / density lines the
+// neighbouring blocks are about to gather: k_project_advect_dens 2.47 -> 2.28 ms.  On grids whose
+// fields fit the MALL the next kernel finds them there, so NT is chosen by size (fluid_api.hip).
+typedef float f2v __attribute__((ext_vector_type(2)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+template <bool NT> __device__ __forceinline__ void store_out(float2 *q, float2 v) {
+  if constexpr (NT) {
+    f2v t = {v.x, v.y};
+    __builtin_nontemporal_store(t, reinterpret_cast<f2v *>(q));
+  } else {
+    *q = v;
+  }
+}
+template <bool NT> __device__ __forceinline__ void store_out(float4 *q, float4 v) {
+  if constexpr (NT) {
+    f4v t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<f4v *>(q));
+  } else {
+    *q = v;
+  }
+}
 // kernel.cu:60-71
 __device__ __forceinline__ float mixf(float x, float y, float a) { return x + (y - x) * a; }
 __device__ __forceinline__ float2 mix(float2 x, float2 y, float a) {
@@ -121,6 +145,7 @@ constexpr int ADV_ROWS_DENS = ADV_RD;  // float4 texels: more rows cost occupanc
   if (x >= g.n) return;
 
 // kernel.cu:114-140
+template <bool NT>
 __global__ __launch_bounds__(BX *BY) void k_advect_vel(Geom g, int r0, int r1, Valid valid, float dt,
                                                         const float2 *__restrict__ vin,
                                                         float2 *__restrict__ vout, int *flag) {
@@ -176,7 +201,7 @@ __global__ __launch_bounds__(BX *BY) void k_advect_vel(Geom g, int r0, int r1, V
   }
 #pragma unroll
   for (int k = 0; k < ADV_ROWS; ++k)
-    if (rbase + k < r1) vout[(size_t)(rbase + k) * g.n + x] = o[k];
+    if (rbase + k < r1) store_out<NT>(vout + (size_t)(rbase + k) * g.n + x, o[k]);
 }
 
 // kernel.cu:142-165
@@ -308,6 +333,7 @@ __global__ __launch_bounds__(BX *BY) void k_project(Geom g, int r0, int r1,
 #define FUSED_BY 4
 #endif
 constexpr int TAIL_BY = FUSED_BY;  // rows per block of the fused kernel
+template <bool NT>
 __global__ __launch_bounds__(BX *TAIL_BY) void k_project_advect_dens(
     Geom g, int r0, int r1, Valid valid, float dt, const float2 *__restrict__ vin,
     const float *__restrict__ p, float2 *__restrict__ vout, const float4 *__restrict__ din,
@@ -319,7 +345,7 @@ __global__ __launch_bounds__(BX *TAIL_BY) void k_project_advect_dens(
   const size_t id = (size_t)r * g.n + x;
   const bool interior = x > 0 && x < g.n - 1 && y > 0 && y < g.n - 1;
   const float2 v = project_cell(g, x, y, r, id, interior, vin, p);
-  vout[id] = v;
+  store_out<NT>(vout + id, v);
   float px = (float)x - dt * v.x;
   float py = (float)y - dt * v.y;
   px = fmaxf(0.0f, fminf(px, (float)g.n));
@@ -329,7 +355,7 @@ __global__ __launch_bounds__(BX *TAIL_BY) void k_project_advect_dens(
   if (__all(tap_inside(tp, g, valid))) o = bilinear_inside(din, g, tp);
   else o = bilinear(din, g, tp, valid, interior ? flag : nullptr);
   if (!interior) o = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-  dout[id] = o;
+  store_out<NT>(dout + id, o);
 }
 
 // kernel.cu:357-383 (every cell, border included)
@@ -391,10 +417,14 @@ const dim3 kBlock(BX, BY);
 }  // namespace
 
 void launch_advect_vel(hipStream_t s, Geom g, int r0, int r1, int vlo, int vhi, float dt,
-                       const float2 *vin, float2 *vout, int *flag) {
+                       const float2 *vin, float2 *vout, int *flag, bool nt) {
   if (r1 <= r0) return;
-  hipLaunchKernelGGL(k_advect_vel, grid_adv(g, r0, r1, ADV_ROWS_VEL), kBlock, 0, s, g, r0, r1, Valid{vlo, vhi}, dt,
-                     vin, vout, flag);
+  if (nt)
+    hipLaunchKernelGGL(k_advect_vel<true>, grid_adv(g, r0, r1, ADV_ROWS_VEL), kBlock, 0, s, g, r0, r1,
+                       Valid{vlo, vhi}, dt, vin, vout, flag);
+  else
+    hipLaunchKernelGGL(k_advect_vel<false>, grid_adv(g, r0, r1, ADV_ROWS_VEL), kBlock, 0, s, g, r0, r1,
+                       Valid{vlo, vhi}, dt, vin, vout, flag);
 }
 void launch_diffuse(hipStream_t s, Geom g, int r0, int r1, float alpha, float beta,
                     const float2 *vin, float2 *vout) {
@@ -417,10 +447,15 @@ void launch_project(hipStream_t s, Geom g, int r0, int r1, const float2 *vin, co
 }
 void launch_project_advect_dens(hipStream_t s, Geom g, int r0, int r1, int vlo, int vhi, float dt,
                                 const float2 *vin, const float *p, float2 *vout, const float4 *din,
-                                float4 *dout, int *flag) {
+                                float4 *dout, int *flag, bool nt) {
   if (r1 <= r0) return;
-  hipLaunchKernelGGL(k_project_advect_dens, dim3((g.n + BX - 1) / BX, (r1 - r0 + TAIL_BY - 1) / TAIL_BY),
-                     dim3(BX, TAIL_BY), 0, s, g, r0, r1, Valid{vlo, vhi}, dt, vin, p, vout, din, dout, flag);
+  const dim3 grid((g.n + BX - 1) / BX, (r1 - r0 + TAIL_BY - 1) / TAIL_BY), block(BX, TAIL_BY);
+  if (nt)
+    hipLaunchKernelGGL(k_project_advect_dens<true>, grid, block, 0, s, g, r0, r1, Valid{vlo, vhi}, dt, vin, p,
+                       vout, din, dout, flag);
+  else
+    hipLaunchKernelGGL(k_project_advect_dens<false>, grid, block, 0, s, g, r0, r1, Valid{vlo, vhi}, dt, vin, p,
+                       vout, din, dout, flag);
 }
 void launch_advect_dens(hipStream_t s, Geom g, int r0, int r1, int vlo, int vhi, float dt,
                         const float2 *vel, const float4 *din, float4 *dout, int *flag) {
