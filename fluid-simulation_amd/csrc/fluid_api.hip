@@ -561,7 +561,7 @@ int fluid_init(fluid_ctx **out, const fluid_params *p) {
   // waves per launch), from sweeps on MI355X (tools/plan_sweep.py, tools/slab_time.py; DESIGN.md
   // 5.1).  Results do not depend on it; FLUID_TILE / FLUID_TB_* override it.
   //   < 2^21  (up to ~1448^2): launch/latency bound -> LDS tiles (fluid_kernels_tile.hip)
-  //   < 2^23  (2048^2)       : 8 / 5 sweeps, 2048 waves (0.257 -> 0.221 ms against 8192 waves)
+  //   < 2^23  (2048^2)       : 8 / 10 sweeps, 2048 waves (0.257 -> 0.201 ms against 8 / 5 sweeps, 8192 waves)
   //   < 2^24  (a slab of 8 of 8192^2)  : 8 / 5 sweeps, one resident round of waves
   //   < 2^25  (4096^2, a slab of 4 of 8192^2): 10 / 10 sweeps, just under one resident round
   //           (4 waves per SIMD x 1024 SIMDs; a few blocks over cost a second round)
@@ -574,13 +574,15 @@ int fluid_init(fluid_ctx **out, const fluid_params *p) {
   c->tb_minchunk = 1;
   if (c->tile) { c->tb_kj = 10; c->tb_kd = 5; }
   else if (owned < (1ll << 21)) { c->tb_kj = 4; }
-  else if (owned < (1ll << 23)) { c->tb_kj = 8; c->tb_kd = 5; c->tb_waves = 2048; }
+  else if (owned < (1ll << 23)) { c->tb_kj = 8; c->tb_kd = 10; c->tb_waves = 2048; }
   else if (owned < (1ll << 24)) { c->tb_kj = 8; c->tb_kd = 5; c->tb_waves = 3900; }
   else if (owned < (1ll << 25)) { c->tb_kj = 10; c->tb_kd = 10; c->tb_waves = 3900; }
   else if (owned < (1ll << 26)) { c->tb_kj = 14; c->tb_kd = 10; c->tb_waves = prm.n >= 12288 ? 3072 : 6100; }
   else if (owned <= (1ll << 27)) { c->tb_kj = 14; c->tb_kd = 10; c->tb_waves = 6100; }
   else { c->tb_kj = 14; c->tb_kd = 10; c->tb_waves = 16384; }
-  c->nt_stores = env_int("FLUID_NT", (long long)prm.n * si.store_rows >= (1ll << 25) ? 1 : 0) != 0;
+  // non-temporal stores in the two streaming kernels (fluid_kernels.hip): measured break-even at
+  // about 3072^2 stored cells (2048^2: 0.204 -> 0.215 ms with them, 4096^2: 0.586 -> 0.570 ms)
+  c->nt_stores = env_int("FLUID_NT", (long long)prm.n * si.store_rows >= (1ll << 24) ? 1 : 0) != 0;
   c->tb_kj = env_int("FLUID_TB_KJ", c->tb_kj);
   c->tb_kd = env_int("FLUID_TB_KD", c->tb_kd);
   c->tb_cj = env_int("FLUID_TB_CJ", c->tb_cj);
