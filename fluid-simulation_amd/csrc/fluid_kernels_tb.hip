@@ -165,7 +165,8 @@ __device__ __forceinline__ void store_row2(float2 *p, const Row2<C> &r) {
 // (wave-uniform test); the steady-state instantiation has neither.
 // ---------------------------------------------------------------------------
 
-// Steady-state row rule in hand-placed ISA (2 columns per lane, strip and rows interior).
+// Row rule in hand-placed ISA (2 columns per lane; every row that is not a y-border row.  A strip at
+// an x border runs it too and then overwrites its border column, see JacobiOp::apply).
 // Same operations in the same order as the C++ expression in apply(); what the asm buys is
 // instruction placement: hipcc folds the lane shifts into v_add_f32_dpp whose tied `old`
 // operand lands on a just-written temporary, so nearly every one is preceded by an s_nop (24
