@@ -18,7 +18,8 @@ for _ in range(reps):
         for k, v in zip(NAMES, spec.split(",")):
             if v.strip():
                 os.environ[k] = v.strip()
-        sim = pkg.FluidSim(n, pressure_iters=J)
+        kw = {"lib": pkg.FluidLib(os.environ["FLUID_LIB_PATH"])} if os.environ.get("FLUID_LIB_PATH") else {}
+        sim = pkg.FluidSim(n, pressure_iters=J, **kw)
         ss = pkg.SplatStream()
         for _i in range(3):
             sim.add_source(*ss.splat())
