@@ -424,7 +424,11 @@ int check_launch(fluid_ctx *c) {
 }
 
 int run_steps(fluid_ctx *c, int nsteps, int parts = FLUID_PART_VELOCITY | FLUID_PART_DENSITY) {
-  const bool direct = (c->prm.flags & FLUID_FLAG_NO_GRAPH) || c->prof;
+  // Parts of one or two kernels are launched directly: a graph launch costs more than the
+  // launches it replaces (measured: 2048-row slab of 16384^2 driven in parts).
+  const int small_parts = FLUID_PART_DENSITY | FLUID_PART_VELOCITY_TAIL | FLUID_PART_TAIL_DENSITY_EDGES |
+                          FLUID_PART_TAIL_DENSITY_INTERIOR;
+  const bool direct = (c->prm.flags & FLUID_FLAG_NO_GRAPH) || c->prof || (env_int("FLUID_DIRECT_PARTS", 1) && (parts & ~small_parts) == 0);
   for (int s = 0; s < nsteps; ++s) {
     if (direct) {
       enq_step(c, parts);
