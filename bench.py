@@ -56,10 +56,23 @@ def measure_single(pkg, n, D, J, steps, warmup, flags=0):
     return sim, wall
 
 
-def cpu_baseline(pkg, D, J, budget_s=12.0):
-    """The serial host-C oracle (oracle/fluid_ref.c, 1 thread) on a bounded sample of the
-    workload: a 1024^2 grid with the workload's D and J, as many steps as fit the budget."""
-    path = os.path.join(ROOT, "oracle", "liboracle_fluid.so")
+def cpu_threads():
+    """Threads for the multi-core baseline: OMP_NUM_THREADS when set (16 on the GPU box: its CPU
+    share; os.cpu_count() shows the whole machine there), else the visible CPUs, at most 16."""
+    try:
+        return max(1, int(os.environ.get("OMP_NUM_THREADS", "")))
+    except ValueError:
+        return max(1, min(16, os.cpu_count() or 1))
+
+
+def cpu_baseline(pkg, D, J, budget_s=12.0, threads=1):
+    """The host-C oracle (oracle/fluid_ref.c) on a bounded sample of the workload: a 1024^2 grid
+    with the workload's D and J, as many steps as fit the budget.  threads=1: the serial build (the
+    contract's `cpu_baseline`); threads>1: the same source built with -fopenmp (bit-identical,
+    tests/test_oracle_kat.py), reported separately as `cpu_baseline_parallel`."""
+    path = os.path.join(ROOT, "oracle", "liboracle_fluid.so" if threads == 1 else "liboracle_fluid_omp.so")
+    if threads > 1:
+        os.environ["OMP_NUM_THREADS"] = str(threads)  # read by libgomp when the library is loaded
     lib = pkg.FluidLib(path)
     n = 1024
     sim = pkg.FluidSim(n, diffusion_iters=D, pressure_iters=J, lib=lib)
@@ -73,9 +86,10 @@ def cpu_baseline(pkg, D, J, budget_s=12.0):
         if el >= budget_s or steps >= 400:
             break
     return {
-        "value": round(n * n * steps / el / 1e9, 6), "unit": "GCUPS", "cores": 1, "kind": "port",
-        "sample": f"{n}x{n} grid, D={D}, J={J}, {steps} steps, seeded splats, serial C oracle "
-                  f"(gcc -O2 -ffp-contract=off), {el:.1f} s",
+        "value": round(n * n * steps / el / 1e9, 6), "unit": "GCUPS", "cores": threads, "kind": "port",
+        "sample": f"{n}x{n} grid, D={D}, J={J}, {steps} steps, seeded splats, "
+                  + ("serial C oracle" if threads == 1 else f"C oracle with OpenMP row loops, {threads} threads")
+                  + f" (gcc -O2 -ffp-contract=off), {el:.1f} s",
     }
 
 
@@ -173,6 +187,9 @@ def main():
         out["other_workloads"] = extra
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(pkg, D, J)
+        nthr = cpu_threads()
+        if nthr > 1 and os.path.exists(os.path.join(ROOT, "oracle", "liboracle_fluid_omp.so")):
+            out["cpu_baseline_parallel"] = cpu_baseline(pkg, D, J, budget_s=6.0, threads=nthr)
     print(json.dumps(out))
 
 

@@ -31,6 +31,16 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* Row loops of the kernels: every output row depends only on the input buffers (read array A,
+ * write array B; add_force touches each cell once), so the rows can be shared out over threads
+ * without changing a bit.  Built serial (liboracle_fluid.so, the checker and the 1-core baseline)
+ * and with -fopenmp (liboracle_fluid_omp.so, the multi-core CPU baseline of bench.py). */
+#ifdef _OPENMP
+#define OMP_ROWS _Pragma("omp parallel for schedule(static)")
+#else
+#define OMP_ROWS
+#endif
+
 typedef struct { float x, y; } f2;
 typedef struct { float x, y, z, w; } f4;
 
@@ -107,6 +117,7 @@ static inline int interior(int x, int y, int n) {
 void ref_advection(int n, float dt, const float *vel_in, float *vel_out) {
   const f2 *vin = (const f2 *)vel_in;
   f2 *vout = (f2 *)vel_out;
+  OMP_ROWS
   for (int y = 0; y < n; ++y)
     for (int x = 0; x < n; ++x) {
       size_t id = x + (size_t)y * n;
@@ -134,6 +145,7 @@ void ref_advection_density(int n, float dt, const float *vel, const float *dens_
   const f2 *v2 = (const f2 *)vel;
   const f4 *din = (const f4 *)dens_in;
   f4 *dout = (f4 *)dens_out;
+  OMP_ROWS
   for (int y = 0; y < n; ++y)
     for (int x = 0; x < n; ++x) {
       size_t id = x + (size_t)y * n;
@@ -157,6 +169,7 @@ void ref_diffusion(int n, float dt, float viscosity, const float *vel_in, float 
   f2 *vout = (f2 *)vel_out;
   float alpha = 1.0f / (viscosity * dt); /* :182 */
   float beta = 1.0f / (4.0f + alpha);    /* :183 */
+  OMP_ROWS
   for (int y = 0; y < n; ++y)
     for (int x = 0; x < n; ++x) {
       size_t id = x + (size_t)y * n;
@@ -176,6 +189,7 @@ void ref_diffusion(int n, float dt, float viscosity, const float *vel_in, float 
 /* kernel.cu:207-230 */
 void ref_vorticity(int n, const float *vel, float *vort) {
   const f2 *v = (const f2 *)vel;
+  OMP_ROWS
   for (int y = 0; y < n; ++y)
     for (int x = 0; x < n; ++x) {
       size_t id = x + (size_t)y * n;
@@ -192,6 +206,7 @@ void ref_vorticity(int n, const float *vel, float *vort) {
 void ref_add_vorticity(int n, float dt, const float *vort, float *vel) {
   f2 *v = (f2 *)vel;
   const float scale = 0.2f; /* :239 */
+  OMP_ROWS
   for (int y = 0; y < n; ++y)
     for (int x = 0; x < n; ++x) {
       size_t id = x + (size_t)y * n;
@@ -215,6 +230,7 @@ void ref_add_vorticity(int n, float dt, const float *vort, float *vel) {
 /* kernel.cu:265-289 */
 void ref_divergence(int n, const float *vel, float *div) {
   const f2 *v = (const f2 *)vel;
+  OMP_ROWS
   for (int y = 0; y < n; ++y)
     for (int x = 0; x < n; ++x) {
       size_t id = x + (size_t)y * n;
@@ -229,6 +245,7 @@ void ref_divergence(int n, const float *vel, float *div) {
 
 /* kernel.cu:291-324 */
 void ref_pressure_jacobi(int n, const float *p_in, const float *div, float *p_out) {
+  OMP_ROWS
   for (int y = 0; y < n; ++y)
     for (int x = 0; x < n; ++x) {
       size_t id = x + (size_t)y * n;
@@ -252,6 +269,7 @@ void ref_pressure_jacobi(int n, const float *p_in, const float *div, float *p_ou
 void ref_projection(int n, const float *vel_in, const float *p, float *vel_out) {
   const f2 *vin = (const f2 *)vel_in;
   f2 *vout = (f2 *)vel_out;
+  OMP_ROWS
   for (int y = 0; y < n; ++y)
     for (int x = 0; x < n; ++x) {
       size_t id = x + (size_t)y * n;
@@ -276,6 +294,7 @@ void ref_add_force(int n, float dt, float radius, float sx, float sy, float fx, 
                    const float rgba[4], float *vel, float *dens) {
   f2 *v = (f2 *)vel;
   f4 *d = (f4 *)dens;
+  OMP_ROWS
   for (int y = 0; y < n; ++y)
     for (int x = 0; x < n; ++x) {
       size_t id = x + (size_t)y * n;

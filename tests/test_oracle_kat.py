@@ -255,3 +255,27 @@ def test_step_is_composition_of_kernels(pkg, oracle, ref):
     assert_bit_equal(sim.read(pkg.FIELD_PRESSURE), p, "pressure")
     assert_bit_equal(sim.read(pkg.FIELD_DIVERGENCE), div, "divergence")
     assert_bit_equal(sim.read(pkg.FIELD_DENSITY), d2, "density")
+
+
+def test_openmp_build_of_the_oracle_gives_the_same_bits(pkg, oracle):
+    """oracle/liboracle_fluid_omp.so (the same source with its row loops shared out over threads;
+    bench.py's multi-core CPU baseline) against the serial build: whole steps with splats and the
+    vorticity stage on, every field bit for bit."""
+    import os
+    from util import ROOT
+    path = os.path.join(ROOT, "oracle", "liboracle_fluid_omp.so")
+    if not os.path.exists(path):
+        pytest.skip("OpenMP build of the oracle not present")
+    os.environ.setdefault("OMP_NUM_THREADS", "4")
+    omp = pkg.FluidLib(path)
+    for n, flags in ((97, 0), (160, pkg.FLAG_VORTICITY)):
+        a = pkg.FluidSim(n, lib=oracle, pressure_iters=12, flags=flags)
+        b = pkg.FluidSim(n, lib=omp, pressure_iters=12, flags=flags)
+        sa, sb = pkg.SplatStream(), pkg.SplatStream()
+        for _ in range(4):
+            a.add_source(*sa.splat())
+            b.add_source(*sb.splat())
+            a.step(3)
+            b.step(3)
+        for f in (pkg.FIELD_VELOCITY, pkg.FIELD_DENSITY, pkg.FIELD_PRESSURE, pkg.FIELD_DIVERGENCE):
+            assert_bit_equal(a.read(f), b.read(f), f"field {f} n={n}")
