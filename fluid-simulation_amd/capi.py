@@ -21,7 +21,7 @@ _FIELD_COMPONENTS = {FIELD_VELOCITY: 2, FIELD_DENSITY: 4, FIELD_PRESSURE: 1, FIE
 # Every symbol include/fluid.h declares (checked against the header text in tests).
 ABI_SYMBOLS = [
     "fluid_default_params", "fluid_init", "fluid_destroy", "fluid_reset", "fluid_add_source",
-    "fluid_step", "fluid_advect_velocity", "fluid_diffuse", "fluid_vorticity", "fluid_project",
+    "fluid_step", "fluid_prepare_steps", "fluid_advect_velocity", "fluid_diffuse", "fluid_vorticity", "fluid_project",
     "fluid_advect_density", "fluid_read", "fluid_write", "fluid_sync", "fluid_diagnostics", "fluid_geometry",
     "fluid_strerror", "fluid_last_error", "fluid_time_steps", "fluid_profile_steps",
     "fluid_stream", "fluid_set_stream",
@@ -117,6 +117,7 @@ class FluidLib:
         sig("fluid_add_source", C.c_int, P, C.c_float, C.c_float, C.c_float, C.c_float,
             C.POINTER(C.c_float))
         sig("fluid_step", C.c_int, P, C.c_int)
+        sig("fluid_prepare_steps", C.c_int, P, C.c_int, required=False)
         for s in ("fluid_advect_velocity", "fluid_diffuse", "fluid_vorticity", "fluid_project",
                   "fluid_advect_density", "fluid_sync"):
             sig(s, C.c_int, P)
@@ -264,6 +265,11 @@ class FluidSim:
 
     def step(self, nsteps: int = 1):
         self._chk(self.lib.dll.fluid_step(self._h, nsteps), "fluid_step")
+
+    def prepare_steps(self, nsteps: int):
+        """fluid_prepare_steps: build the graphs step(nsteps) replays, without running anything."""
+        if hasattr(self.lib.dll, "fluid_prepare_steps"):
+            self._chk(self.lib.dll.fluid_prepare_steps(self._h, nsteps), "fluid_prepare_steps")
 
     def advect_velocity(self):
         self._chk(self.lib.dll.fluid_advect_velocity(self._h), "fluid_advect_velocity")

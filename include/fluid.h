@@ -123,6 +123,13 @@ FLUID_API int fluid_add_source(fluid_ctx *ctx, float sx, float sy, float fx, flo
  * FLUID_FLAG_NO_GRAPH); no host synchronisation is implied. */
 FLUID_API int fluid_step(fluid_ctx *ctx, int nsteps);
 
+/* Build (capture and instantiate) the graphs fluid_step(ctx, nsteps) will replay, without running
+ * anything: whole steps are captured in power-of-two batches per graph (21 steps = 16 + 4 + 1, at
+ * most FLUID_GRAPH_STEPS = 16 per graph), one graph per batch size and ping-pong state, built on
+ * first use otherwise.  No counterpart in the reference (it launches kernel by kernel); for
+ * callers that want the first fluid_step of a given length to cost what the later ones do. */
+FLUID_API int fluid_prepare_steps(fluid_ctx *ctx, int nsteps);
+
 /* The four stage functions simulationStep() is made of, individually
  * (kernel.cu:542-555, :582-602, :604-662, :664-685) and the optional
  * simulateVorticity() (:557-580).  fluid_step == advect_velocity, diffuse,

@@ -452,6 +452,8 @@ int fluid_step(fluid_ctx *c, int nsteps) {
 }
 
 /* kernel.cu:687-699 */
+int fluid_prepare_steps(fluid_ctx *c, int nsteps) { return c && nsteps >= 0 ? FLUID_OK : FLUID_E_INVALID; }
+
 int fluid_add_source(fluid_ctx *c, float sx, float sy, float fx, float fy, const float rgba[4]) {
   if (!c || !rgba) return FLUID_E_INVALID;
   ref_add_force(c->prm.n, c->prm.dt, c->prm.splat_radius, sx, sy, fx, fy, rgba, c->vel[c->vin],

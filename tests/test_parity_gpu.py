@@ -141,6 +141,31 @@ def test_graph_replay_equals_direct_launch(pkg, hip):
         assert_bit_equal(a[f], b[f], f)
 
 
+@pytest.mark.parametrize("D,J", [(3, 11), (2, 8), (1, 1), (0, 0)])
+def test_several_steps_per_graph_equal_single_steps(pkg, hip, D, J, monkeypatch):
+    """fluid_step(n) captures whole steps in power-of-two batches per graph (37 = 32 + 4 + 1 with
+    FLUID_GRAPH_STEPS=32); every ping-pong parity (odd / even D and J), a second call that reuses
+    the cached graphs from another starting state, against one step per call and direct launches."""
+    n = 150
+    monkeypatch.setenv("FLUID_GRAPH_STEPS", "32")
+    batched = pkg.FluidSim(n, lib=hip, diffusion_iters=D, pressure_iters=J)
+    monkeypatch.setenv("FLUID_GRAPH_STEPS", "1")
+    single = pkg.FluidSim(n, lib=hip, diffusion_iters=D, pressure_iters=J)
+    direct = pkg.FluidSim(n, lib=hip, diffusion_iters=D, pressure_iters=J, flags=pkg.FLAG_NO_GRAPH)
+    streams = [pkg.SplatStream() for _ in range(3)]
+    for count in (37, 5, 16):
+        for sim, ss in zip((batched, single, direct), streams):
+            sim.add_source(*ss.splat())
+        batched.step(count)
+        direct.step(count)
+        for _ in range(count):
+            single.step(1)
+        a, b, c = read_all(batched, pkg), read_all(single, pkg), read_all(direct, pkg)
+        for f in FIELDS:
+            assert_bit_equal(a[f], b[f], f"{f} batched vs single after {count}")
+            assert_bit_equal(a[f], c[f], f"{f} batched vs direct after {count}")
+
+
 def test_read_rejects_small_buffer_and_unknown_field(pkg, hip):
     import ctypes as C
     gpu = pkg.FluidSim(16, lib=hip)
