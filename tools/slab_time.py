@@ -16,7 +16,8 @@ n, J, G = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 rank = int(sys.argv[4]) if len(sys.argv) > 4 else G // 2
 groups = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 LIB = {"lib": pkg.FluidLib(os.environ["FLUID_LIB_PATH"])} if os.environ.get("FLUID_LIB_PATH") else {}
-sim = pkg.FluidSim(n, pressure_iters=J, slab_rank=rank, slab_count=G, pressure_groups=groups, **LIB)
+sim = pkg.FluidSim(n, pressure_iters=J, slab_rank=rank, slab_count=G, pressure_groups=groups,
+                   flags=int(os.environ.get("FLUID_SLAB_FLAGS", "0")), **LIB)
 
 
 def velocity_part(tail=True):
