@@ -579,7 +579,9 @@ int fluid_init(fluid_ctx **out, const fluid_params *p) {
   // Launch plan by owned cells (sweeps per launch for the pressure / diffusion loops, target
   // waves per launch), from sweeps on MI355X (tools/plan_sweep.py, tools/slab_time.py; DESIGN.md
   // 5.1).  Results do not depend on it; FLUID_TILE / FLUID_TB_* override it.
-  //   < 2^21  (up to ~1448^2): launch/latency bound -> LDS tiles (fluid_kernels_tile.hip)
+  //   <= 2^20 (up to 1024^2): launch/latency bound -> LDS tiles (fluid_kernels_tile.hip), 10 / 10
+  //           sweeps per launch; one resident round of 64 x 32 tiles ends at 1024^2 (1088^2: 0.131 ms
+  //           against 0.123 ms for the pipeline)
   //   < 2^23  (2048^2)       : 8 / 10 sweeps, 2048 waves (0.257 -> 0.201 ms against 8 / 5 sweeps, 8192 waves)
   //   < 2^24  (a slab of 8 of 8192^2)  : 8 / 5 sweeps, one resident round of waves
   //   < 2^25  (4096^2, a slab of 4 of 8192^2): 10 / 10 sweeps, just under one resident round
@@ -589,10 +591,9 @@ int fluid_init(fluid_ctx **out, const fluid_params *p) {
   //   <= 2^27 (8192^2, slabs of 4 or 2 of 16384^2): 14 / 10 sweeps, two rounds
   //   above   (16384^2)      : 14 / 10 sweeps, 16384 waves (shorter chunks even out the tail)
   const long long owned = (long long)prm.n * si.rows;
-  c->tile = env_int("FLUID_TILE", owned < (1ll << 21) ? 1 : 0) != 0;
+  c->tile = env_int("FLUID_TILE", owned <= (1ll << 20) ? 1 : 0) != 0;
   c->tb_minchunk = 1;
-  if (c->tile) { c->tb_kj = 10; c->tb_kd = 5; }
-  else if (owned < (1ll << 21)) { c->tb_kj = 4; }
+  if (c->tile) { c->tb_kj = 10; c->tb_kd = 10; }
   else if (owned < (1ll << 23)) { c->tb_kj = 8; c->tb_kd = 10; c->tb_waves = 2048; }
   else if (owned < (1ll << 24)) { c->tb_kj = 8; c->tb_kd = 5; c->tb_waves = 3900; }
   else if (owned < (1ll << 25)) { c->tb_kj = 10; c->tb_kd = 10; c->tb_waves = 3900; }

@@ -9,7 +9,7 @@ n, J = int(sys.argv[1]), int(sys.argv[2])
 specs = sys.argv[3].split(";")
 steps = int(sys.argv[4]) if len(sys.argv) > 4 else 100
 reps = int(sys.argv[5]) if len(sys.argv) > 5 else 3
-NAMES = ("FLUID_TB_KJ", "FLUID_TB_KD", "FLUID_TB_WAVES", "FLUID_NT")
+NAMES = ("FLUID_TB_KJ", "FLUID_TB_KD", "FLUID_TB_WAVES", "FLUID_NT", "FLUID_TILE")
 res = {s: [] for s in specs}
 for _ in range(reps):
     for spec in specs:
