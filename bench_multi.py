@@ -24,7 +24,14 @@ def run_multi(pkg, args, n, D, J, flags):
         local = 0
     torch.cuda.set_device(local)
     if backend == "nccl":
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        kw = {}
+        try:  # RCCL's own streams at high priority too: see SlabSim.comm_stream
+            opts = dist.ProcessGroupNCCL.Options()
+            opts.is_high_priority_stream = True
+            kw["pg_options"] = opts
+        except Exception:
+            pass
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local), **kw)
     else:
         dist.init_process_group(backend, rank=rank, world_size=world)
 

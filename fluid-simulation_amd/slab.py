@@ -119,7 +119,10 @@ class SlabSim:
         self.torch = torch
         torch.cuda.set_device(device_index)
         self.stream = torch.cuda.Stream(device=device_index)       # kernels, unpack
-        self.comm_stream = torch.cuda.Stream(device=device_index)  # pack, transfers
+        # pack, transfers: high priority, so that it never shares a hardware queue with the
+        # compute stream (4 per process on the target boxes, streams are mapped round-robin within
+        # a priority level) and its short kernels are dispatched while a long launch fills the CUs
+        self.comm_stream = torch.cuda.Stream(device=device_index, priority=-1)
         self.sim = pkg.FluidSim(n, device=device_index, slab_rank=rank, slab_count=world, **params)
         self.sim.set_stream(self.stream.cuda_stream)
         self.n, self.row0, self.rows = self.sim.n, self.sim.row0, self.sim.rows
