@@ -61,6 +61,7 @@ struct fluid_ctx {
   bool tile = false;  // small grids: LDS-tiled sweeps (fluid_kernels_tile.hip) instead of the register pipeline
   bool nt_stores = false;  // grids far beyond the caches: non-temporal stores in the two streaming kernels
   int graph_steps = 1;     // whole steps captured per graph (fluid_step)
+  int interior_split = 4;  // launches FLUID_PART_TAIL_DENSITY_INTERIOR is cut into (at most)
   bool prof = false;
   std::vector<hipEvent_t> ev_pool;
   size_t ev_used = 0;
@@ -360,9 +361,23 @@ void enq_gradient_density_rows(fluid_ctx *c, bool edges) {
   // EDGES reads the current buffers and writes the other halves, then flips; INTERIOR runs after
   // the flip, so its input is the other half and its output the current one.
   const int vi = edges ? c->vin : c->vin ^ 1, di = edges ? c->din : c->din ^ 1;
-  const Range parts[2] = {edges ? Range{own.r0, lo_end} : Range{lo_end, hi_beg},
-                          edges ? Range{hi_beg, own.r1} : Range{0, 0}};
-  for (const Range &r : parts) {
+  // The interior goes out as a few launches, not one: work queued on another stream meanwhile (the
+  // halo messages) is sure of a way in at each boundary (a kernel of few, large
+  // workgroups did not get in while one long launch kept every CU refilled).
+  Range parts[8];
+  int np = 0;
+  if (edges) {
+    parts[np++] = Range{own.r0, lo_end};
+    parts[np++] = Range{hi_beg, own.r1};
+  } else {
+    const int rows = hi_beg - lo_end;
+    int k = c->interior_split;
+    while (k > 1 && (double)c->g.n * rows / k < (double)(1 << 21)) --k;  // keep every piece a full launch
+    for (int i = 0; i < k; ++i)
+      parts[np++] = Range{lo_end + (int)((long)rows * i / k), lo_end + (int)((long)rows * (i + 1) / k)};
+  }
+  for (int i = 0; i < np; ++i) {
+    const Range r = parts[i];
     if (r.r1 <= r.r0) continue;
     ProfScope p(c, K_PROJECT_ADVECT_DENS, 60.0 * (double)c->g.n * (r.r1 - r.r0));
     launch_project_advect_dens(c->stream, c->g, r.r0, r.r1, valid.r0, valid.r1, c->prm.dt,
@@ -605,6 +620,8 @@ int fluid_init(fluid_ctx **out, const fluid_params *p) {
   c->nt_stores = env_int("FLUID_NT", (long long)prm.n * si.store_rows >= (1ll << 24) ? 1 : 0) != 0;
   c->graph_steps = env_int("FLUID_GRAPH_STEPS", 16);
   if (c->graph_steps < 1) c->graph_steps = 1;
+  c->interior_split = env_int("FLUID_INTERIOR_SPLIT", 4);
+  c->interior_split = c->interior_split < 1 ? 1 : c->interior_split > 8 ? 8 : c->interior_split;
   c->tb_kj = env_int("FLUID_TB_KJ", c->tb_kj);
   c->tb_kd = env_int("FLUID_TB_KD", c->tb_kd);
   c->tb_cj = env_int("FLUID_TB_CJ", c->tb_cj);
