@@ -62,6 +62,7 @@ struct fluid_ctx {
   bool nt_stores = false;  // grids far beyond the caches: non-temporal stores in the two streaming kernels
   int graph_steps = 1;     // whole steps captured per graph (fluid_step)
   int interior_split = 4;  // launches FLUID_PART_TAIL_DENSITY_INTERIOR is cut into (at most)
+  int interior_piece_min = 1 << 21;  // ... each of at least this many cells
   bool prof = false;
   std::vector<hipEvent_t> ev_pool;
   size_t ev_used = 0;
@@ -372,7 +373,7 @@ void enq_gradient_density_rows(fluid_ctx *c, bool edges) {
   } else {
     const int rows = hi_beg - lo_end;
     int k = c->interior_split;
-    while (k > 1 && (double)c->g.n * rows / k < (double)(1 << 21)) --k;  // keep every piece a full launch
+    while (k > 1 && (double)c->g.n * rows / k < (double)c->interior_piece_min) --k;  // keep every piece a full launch
     for (int i = 0; i < k; ++i)
       parts[np++] = Range{lo_end + (int)((long)rows * i / k), lo_end + (int)((long)rows * (i + 1) / k)};
   }
@@ -622,6 +623,7 @@ int fluid_init(fluid_ctx **out, const fluid_params *p) {
   if (c->graph_steps < 1) c->graph_steps = 1;
   c->interior_split = env_int("FLUID_INTERIOR_SPLIT", 4);
   c->interior_split = c->interior_split < 1 ? 1 : c->interior_split > 8 ? 8 : c->interior_split;
+  c->interior_piece_min = env_int("FLUID_INTERIOR_PIECE_MIN", 1 << 21);
   c->tb_kj = env_int("FLUID_TB_KJ", c->tb_kj);
   c->tb_kd = env_int("FLUID_TB_KD", c->tb_kd);
   c->tb_cj = env_int("FLUID_TB_CJ", c->tb_cj);
