@@ -25,12 +25,13 @@ def run_multi(pkg, args, n, D, J, flags):
     torch.cuda.set_device(local)
     if backend == "nccl":
         kw = {}
-        try:  # RCCL's own streams at high priority too: see SlabSim.comm_stream
-            opts = dist.ProcessGroupNCCL.Options()
-            opts.is_high_priority_stream = True
-            kw["pg_options"] = opts
-        except Exception:
-            pass
+        if os.environ.get("FLUID_SLAB_HIGH_PRIORITY", "0") == "1":  # see SlabSim.comm_stream: off by default
+            try:
+                opts = dist.ProcessGroupNCCL.Options()
+                opts.is_high_priority_stream = True
+                kw["pg_options"] = opts
+            except Exception:
+                pass
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local), **kw)
     else:
         dist.init_process_group(backend, rank=rank, world_size=world)

@@ -134,6 +134,30 @@ def test_slabs_with_split_tail_equal_whole_domain(pkg, hip, count, n, D, J, A, G
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("pieces", [1, 3, 8])
+def test_interior_of_the_split_tail_in_several_launches(pkg, hip, pieces, monkeypatch):
+    """FLUID_PART_TAIL_DENSITY_INTERIOR goes out as several launches so that halo traffic queued on
+    another stream gets in between them.  Any number of pieces, also more pieces
+    than rows would fill: the bits of the whole-domain run."""
+    import fluid_simulation_amd.slab as slab
+    monkeypatch.setenv("FLUID_INTERIOR_SPLIT", str(pieces))
+    monkeypatch.setenv("FLUID_INTERIOR_PIECE_MIN", "1")
+    n, count = 384, 2
+    whole = pkg.FluidSim(n, pressure_iters=12)
+    group = slab.LocalSlabGroup(pkg, n, count, split_tail=True, pressure_iters=12, halo_rows=3)
+    ss_a, ss_b = pkg.SplatStream(), pkg.SplatStream()
+    for s in range(4):
+        whole.add_source(*ss_a.splat())
+        group.add_source(*ss_b.splat())
+        whole.step(1)
+        group.step(1)
+    for f, fid in (("velocity", pkg.FIELD_VELOCITY), ("density", pkg.FIELD_DENSITY), ("pressure", pkg.FIELD_PRESSURE)):
+        assert_bit_equal(group.read(fid), whole.read(fid), f"{f} pieces={pieces}")
+    group.close()
+    whole.close()
+
+
+@pytest.mark.gpu
 def test_slabs_long_backtraces_and_halo_violation(pkg, hip):
     """Backtraces of several rows are fine while they stay within halo_rows; one that leaves it
     must be reported (FLUID_E_HALO), never silently wrong."""

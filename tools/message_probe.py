@@ -14,7 +14,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 G = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 sim = pkg.FluidSim(n, pressure_iters=40, slab_rank=G // 2, slab_count=G)
 comp = torch.cuda.Stream()
-side = torch.cuda.Stream(priority=-1)
+side = torch.cuda.Stream(priority=-1 if os.environ.get("PROBE_HIGH_PRIORITY", "0") == "1" else 0)
 sim.set_stream(comp.cuda_stream)
 ss = pkg.SplatStream()
 sim.add_source(*ss.splat())
