@@ -273,10 +273,12 @@ enum {
   FLUID_PART_VELOCITY_HEAD = 4,
   FLUID_PART_PRESSURE_GROUP = 8,
   FLUID_PART_VELOCITY_TAIL = 16,
-  /* VELOCITY_TAIL + DENSITY as the one fused kernel, in two launches: first the owned rows that
+  /* VELOCITY_TAIL + DENSITY as the one fused kernel, in two parts: first the owned rows that
    * the next exchange sends (within halo_vel rows of a neighbouring slab), then the rest, so that
    * both halo messages travel while the interior is computed.  EDGES flips the current buffers:
-   * after it fluid_halo_pack_part sends the new edge rows. */
+   * after it fluid_halo_pack_part sends the new edge rows.  INTERIOR is enqueued as up to 4
+   * launches over consecutive row ranges (env FLUID_INTERIOR_SPLIT, 1..8) so that work queued on
+   * another stream in the meantime is dispatched at a launch boundary at the latest. */
   FLUID_PART_TAIL_DENSITY_EDGES = 32,
   FLUID_PART_TAIL_DENSITY_INTERIOR = 64
 };
