@@ -969,8 +969,8 @@ int fluid_halo_pack_part(fluid_ctx *c, int dir, int part, void *dst, void *strea
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
   const size_t row = (size_t)c->g.n * f.esize;
   const size_t r = dir < 0 ? c->own_r0 : c->own_r0 + c->rows - f.rows;  // owned rows next to that neighbour
-  HIPCHK(c, hipMemcpyAsync(dst, f.base + r * row, f.rows * row, hipMemcpyDeviceToDevice, st));
-  return FLUID_OK;
+  launch_copy_block(st, dst, f.base + r * row, f.rows * row);
+  return check_launch(c);
 }
 
 int fluid_halo_unpack_part(fluid_ctx *c, int dir, int part, const void *src, void *stream) {
@@ -981,8 +981,8 @@ int fluid_halo_unpack_part(fluid_ctx *c, int dir, int part, const void *src, voi
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
   const size_t row = (size_t)c->g.n * f.esize;
   const size_t r = dir < 0 ? c->own_r0 - f.rows : c->own_r0 + c->rows;  // halo rows just outside the owned rows
-  HIPCHK(c, hipMemcpyAsync(f.base + r * row, src, f.rows * row, hipMemcpyDeviceToDevice, st));
-  return FLUID_OK;
+  launch_copy_block(st, f.base + r * row, src, f.rows * row);
+  return check_launch(c);
 }
 
 // Message layout: [halo_vel rows of float2][halo_dens rows of float4], rows in ascending y.
@@ -995,10 +995,9 @@ int fluid_halo_pack(fluid_ctx *c, int dir, void *dst) {
   // the owned rows adjacent to that neighbour
   const size_t rv = dir < 0 ? c->own_r0 : c->own_r0 + c->rows - c->halo_vel;
   const size_t rd = dir < 0 ? c->own_r0 : c->own_r0 + c->rows - c->halo_dens;
-  HIPCHK(c, hipMemcpyAsync(dst, c->vel[c->vin] + rv * n, vb, hipMemcpyDeviceToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync((char *)dst + vb, c->dens[c->din] + rd * n, db, hipMemcpyDeviceToDevice,
-                           c->stream));
-  return FLUID_OK;
+  launch_copy_block(c->stream, dst, c->vel[c->vin] + rv * n, vb);
+  launch_copy_block(c->stream, (char *)dst + vb, c->dens[c->din] + rd * n, db);
+  return check_launch(c);
 }
 
 int fluid_halo_unpack(fluid_ctx *c, int dir, const void *src) {
@@ -1010,10 +1009,9 @@ int fluid_halo_unpack(fluid_ctx *c, int dir, const void *src) {
   // the halo rows just outside the owned rows on that side
   const size_t rv = dir < 0 ? c->own_r0 - c->halo_vel : c->own_r0 + c->rows;
   const size_t rd = dir < 0 ? c->own_r0 - c->halo_dens : c->own_r0 + c->rows;
-  HIPCHK(c, hipMemcpyAsync(c->vel[c->vin] + rv * n, src, vb, hipMemcpyDeviceToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->dens[c->din] + rd * n, (const char *)src + vb, db,
-                           hipMemcpyDeviceToDevice, c->stream));
-  return FLUID_OK;
+  launch_copy_block(c->stream, c->vel[c->vin] + rv * n, src, vb);
+  launch_copy_block(c->stream, c->dens[c->din] + rd * n, (const char *)src + vb, db);
+  return check_launch(c);
 }
 
 void *fluid_stream(fluid_ctx *c) { return c ? (void *)c->stream : nullptr; }

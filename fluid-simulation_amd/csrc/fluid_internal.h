@@ -41,6 +41,7 @@ extern const char *const kKernelNames[K_COUNT];
 // [vlo, vhi): local rows of the gathered field that hold current data; a
 // backtrace outside raises *halo_flag.
 // nt: non-temporal stores of the output (grids far beyond the caches, see fluid_kernels.hip)
+void launch_copy_block(hipStream_t s, void *dst, const void *src, size_t bytes);  // bytes % 4 == 0
 void launch_advect_vel(hipStream_t s, Geom g, int r0, int r1, int vlo, int vhi, float dt,
                        const float2 *vin, float2 *vout, int *halo_flag, bool nt);
 void launch_diffuse(hipStream_t s, Geom g, int r0, int r1, float alpha, float beta,

@@ -405,6 +405,16 @@ __global__ __launch_bounds__(BX *BY) void k_add_vorticity(Geom g, int r0, int r1
   }
 }
 
+// Halo blocks (whole rows, contiguous) to and from the staging buffers.  Not hipMemcpyAsync: its
+// blit kernel has few, large workgroups, which are not dispatched while a long launch on another
+// stream keeps every CU refilled (the pack then waited for the end of the interior
+// launch it is meant to overlap).  Many 256-thread workgroups get in at once.
+template <typename T>
+__global__ __launch_bounds__(256) void k_copy_block(const T *__restrict__ src, T *__restrict__ dst, size_t count) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < count) dst[i] = src[i];
+}
+
 inline dim3 grid_for(Geom g, int r0, int r1) {
   return dim3((g.n + BX - 1) / BX, (r1 - r0 + BY - 1) / BY);
 }
@@ -416,6 +426,18 @@ const dim3 kBlock(BX, BY);
 
 }  // namespace
 
+void launch_copy_block(hipStream_t s, void *dst, const void *src, size_t bytes) {
+  if (!bytes) return;
+  if (((uintptr_t)dst | (uintptr_t)src | bytes) % 16 == 0) {
+    const size_t count = bytes / 16;
+    hipLaunchKernelGGL(k_copy_block<uint4>, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s,
+                       (const uint4 *)src, (uint4 *)dst, count);
+  } else {  // every field element is a multiple of 4 bytes
+    const size_t count = bytes / 4;
+    hipLaunchKernelGGL(k_copy_block<unsigned>, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s,
+                       (const unsigned *)src, (unsigned *)dst, count);
+  }
+}
 void launch_advect_vel(hipStream_t s, Geom g, int r0, int r1, int vlo, int vhi, float dt,
                        const float2 *vin, float2 *vout, int *flag, bool nt) {
   if (r1 <= r0) return;

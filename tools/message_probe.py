@@ -25,7 +25,9 @@ dst = torch.empty_like(src)
 ev = lambda: torch.cuda.Event(enable_timing=True)
 
 def message(kind):
-    if kind == "blit":
+    if kind == "pack":   # the library's own pack of the velocity block for the lower neighbour
+        sim.halo_pack_part(-1, pkg.PART_VELOCITY, dst.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    elif kind == "blit":
         dst.copy_(src, non_blocking=True)
     else:
         torch.add(src, 1.0, out=dst)
@@ -55,7 +57,7 @@ def one(kind, where):
     torch.cuda.synchronize()
     return t0.elapsed_time(t1), s0.elapsed_time(s1), t0.elapsed_time(s0), t0.elapsed_time(s1)
 
-for kind in ("blit", "elementwise"):
+for kind in ("pack", "blit", "elementwise"):
     torch.cuda.synchronize()
     a, b = ev(), ev()
     message(kind); message(kind); torch.cuda.synchronize(); a.record(); message(kind); b.record(); torch.cuda.synchronize()
