@@ -31,6 +31,7 @@ ABI_SYMBOLS = [
 PART_VELOCITY, PART_DENSITY = 1, 2
 PART_VELOCITY_HEAD, PART_PRESSURE_GROUP, PART_VELOCITY_TAIL = 4, 8, 16
 PART_TAIL_DENSITY_EDGES, PART_TAIL_DENSITY_INTERIOR = 32, 64
+PART_ADVECT_INTERIOR = 128
 
 
 class FluidParams(C.Structure):

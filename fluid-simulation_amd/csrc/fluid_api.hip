@@ -41,6 +41,7 @@ struct fluid_ctx {
   int groups = 1, jg = 0, halo_prs = 0;  // pressure groups: count, sweeps per group, rows exchanged
   int pgroup = 0;                        // next pressure group to run in the current step
   bool tail_edges_done = false;          // FLUID_PART_TAIL_DENSITY_EDGES ran, INTERIOR pending
+  bool advect_early = false;             // FLUID_PART_ADVECT_INTERIOR ran for the step about to start
   bool slab = false, has_lo = false, has_hi = false;
   float2 *vel[2] = {nullptr, nullptr};   // velocityBufferArray[2]  kernel.cu:443-444
   float4 *dens[2] = {nullptr, nullptr};  // densityBufferArray[2]   kernel.cu:447-448
@@ -146,14 +147,45 @@ Range widened(const fluid_ctx *c, int m) {
   return Range{c->own_r0 - (m < lo ? m : lo), c->own_r0 + c->rows + (m < hi ? m : hi)};
 }
 
+// The owned rows at least halo_vel rows away from a neighbouring slab: no neighbour waits for
+// them at the end of a step (FLUID_PART_TAIL_DENSITY_INTERIOR) and they need no halo row at the
+// start of the next (FLUID_PART_ADVECT_INTERIOR).  Empty on a slab shorter than two halos.
+Range interior_band(const fluid_ctx *c) {
+  const Range own = widened(c, 0);
+  const int h = c->halo_vel < own.r1 - own.r0 ? c->halo_vel : own.r1 - own.r0;
+  const int lo_end = c->has_lo ? own.r0 + h : own.r0;
+  const int hi_beg = c->has_hi ? (own.r1 - h > lo_end ? own.r1 - h : lo_end) : own.r1;
+  return Range{lo_end, hi_beg};
+}
+
 // simulateAdvection()  kernel.cu:542-555.  out_m: halo margin the result must cover.
 void enq_advect_velocity(fluid_ctx *c, int out_m) {
   const double cells = (double)cells_owned(c);
-  ProfScope p(c, K_ADVECT_VEL, 16.0 * cells);
   const Range r = widened(c, out_m);
-  launch_advect_vel(c->stream, c->g, r.r0, r.r1, 0, c->g.L, c->prm.dt, c->vel[c->vin],
-                    c->vel[c->vin ^ 1], c->halo_flag, c->nt_stores);
+  // after FLUID_PART_ADVECT_INTERIOR only the rows on either side of the interior band are left
+  const Range band = c->advect_early ? interior_band(c) : Range{r.r1, r.r1};
+  const Range todo[2] = {Range{r.r0, band.r0}, Range{band.r1, r.r1}};
+  for (const Range &t : todo) {
+    if (t.r1 <= t.r0) continue;
+    ProfScope p(c, K_ADVECT_VEL, 16.0 * cells * (t.r1 - t.r0) / (r.r1 - r.r0));
+    launch_advect_vel(c->stream, c->g, t.r0, t.r1, 0, c->g.L, c->prm.dt, c->vel[c->vin],
+                      c->vel[c->vin ^ 1], c->halo_flag, c->nt_stores);
+  }
+  c->advect_early = false;
   c->vin ^= 1;
+}
+
+// The interior band's share of the next step's advection, before that step's velocity halos have
+// arrived: same kernel, same inputs (owned rows of the current velocity), same outputs.  A
+// backtrace that leaves the owned rows (more than halo_vel rows long) raises the halo flag.
+void enq_advect_interior(fluid_ctx *c) {
+  const Range band = interior_band(c), own = widened(c, 0);
+  if (band.r1 > band.r0) {
+    ProfScope p(c, K_ADVECT_VEL, 16.0 * (double)c->g.n * (band.r1 - band.r0));
+    launch_advect_vel(c->stream, c->g, band.r0, band.r1, own.r0, own.r1, c->prm.dt, c->vel[c->vin],
+                      c->vel[c->vin ^ 1], c->halo_flag, c->nt_stores);
+  }
+  c->advect_early = true;
 }
 
 int env_int(const char *name, int dflt) {
@@ -354,10 +386,8 @@ void enq_gradient(fluid_ctx *c, bool with_density) {
 // The fused gradient subtraction + density advection on a sub-range of the owned rows: the rows
 // within halo_vel of a neighbouring slab (edges: what the next exchange sends) or the rest.
 void enq_gradient_density_rows(fluid_ctx *c, bool edges) {
-  const Range own = widened(c, 0);
-  const int h = c->halo_vel < own.r1 - own.r0 ? c->halo_vel : own.r1 - own.r0;
-  const int lo_end = c->has_lo ? own.r0 + h : own.r0;                       // [own.r0, lo_end)
-  const int hi_beg = c->has_hi ? (own.r1 - h > lo_end ? own.r1 - h : lo_end) : own.r1;  // [hi_beg, own.r1)
+  const Range own = widened(c, 0), band = interior_band(c);
+  const int lo_end = band.r0, hi_beg = band.r1;  // edges: [own.r0, lo_end) and [hi_beg, own.r1)
   const Range valid = c->slab ? widened(c, c->halo_dens) : Range{0, c->g.L};
   // EDGES reads the current buffers and writes the other halves, then flips; INTERIOR runs after
   // the flip, so its input is the other half and its output the current one.
@@ -418,6 +448,7 @@ void enq_velocity_head(fluid_ctx *c) {
   enq_pressure_group(c, 0);
 }
 void enq_step(fluid_ctx *c, int parts) {
+  if (parts & FLUID_PART_ADVECT_INTERIOR) enq_advect_interior(c);
   if (parts & FLUID_PART_VELOCITY) {  // one pressure group (checked by the callers)
     enq_velocity_head(c);
     // When the whole step is enqueued at once, the gradient subtraction and the density
@@ -445,7 +476,7 @@ int run_steps(fluid_ctx *c, int nsteps, int parts = FLUID_PART_VELOCITY | FLUID_
   // Parts of one or two kernels are launched directly: a graph launch costs more than the
   // launches it replaces (measured: 2048-row slab of 16384^2 driven in parts).
   const int small_parts = FLUID_PART_DENSITY | FLUID_PART_VELOCITY_TAIL | FLUID_PART_TAIL_DENSITY_EDGES |
-                          FLUID_PART_TAIL_DENSITY_INTERIOR;
+                          FLUID_PART_TAIL_DENSITY_INTERIOR | FLUID_PART_ADVECT_INTERIOR;
   const bool direct = (c->prm.flags & FLUID_FLAG_NO_GRAPH) || c->prof || (env_int("FLUID_DIRECT_PARTS", 1) && (parts & ~small_parts) == 0);
   // Whole steps of a whole-domain context are captured several to a graph, in power-of-two batches
   // (21 steps = 16 + 4 + 1): a graph launch costs 4-5 us of its own on this runtime, 12 % of the
@@ -465,22 +496,26 @@ int run_steps(fluid_ctx *c, int nsteps, int parts = FLUID_PART_VELOCITY | FLUID_
     }
     int batch = 1;
     while (batch * 2 <= per_graph && batch * 2 <= nsteps - s) batch *= 2;
-    const int key = state_of(c) | (parts << 3) | ((c->pgroup & 0xfff) << 12) | (batch << 24);
+    const int key = state_of(c) | (parts << 3) | (c->advect_early ? 1 << 11 : 0) | ((c->pgroup & 0xfff) << 12) |
+                    (batch << 24);
     auto it = c->graphs.find(key);
     s += batch;
     if (it == c->graphs.end()) {
       GraphEntry ge;
+      const bool early0 = c->advect_early;  // consumed by the enqueue; the launch below clears it
       HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
       for (int b = 0; b < batch; ++b) enq_step(c, parts);
       hipError_t e = hipStreamEndCapture(c->stream, &ge.graph);
       ge.next_state = state_of(c);
       set_state(c, key & 7);
+      c->advect_early = early0;
       if (e != hipSuccess) return fail(c, FLUID_E_DEVICE, "hipStreamEndCapture: %s", hipGetErrorString(e));
       HIPCHK(c, hipGraphInstantiate(&ge.exec, ge.graph, nullptr, nullptr, 0));
       it = c->graphs.emplace(key, ge).first;
     }
     if (launch) HIPCHK(c, hipGraphLaunch(it->second.exec, c->stream));
     set_state(c, it->second.next_state);
+    if (launch && (parts & (FLUID_PART_VELOCITY | FLUID_PART_VELOCITY_HEAD))) c->advect_early = false;
   }
   if (!launch) set_state(c, state0);
   return FLUID_OK;
@@ -698,6 +733,7 @@ void fluid_destroy(fluid_ctx *c) {
 
 int fluid_reset(fluid_ctx *c) {
   if (!c) return FLUID_E_INVALID;
+  c->advect_early = false;  // rows advected ahead of the step are stale now (recomputed by the full launch)
   HIPCHK(c, hipSetDevice(c->prm.device));
   const size_t nc = cells_local(c);
   HIPCHK(c, hipMemsetAsync(c->vel[c->vin], 0, nc * sizeof(float2), c->stream));
@@ -708,6 +744,7 @@ int fluid_reset(fluid_ctx *c) {
 
 int fluid_add_source(fluid_ctx *c, float sx, float sy, float fx, float fy, const float rgba[4]) {
   if (!c || !rgba) return FLUID_E_INVALID;
+  c->advect_early = false;  // rows advected ahead of the step are stale now (recomputed by the full launch)
   HIPCHK(c, hipSetDevice(c->prm.device));
   ProfScope p(c, K_ADD_FORCE, 48.0 * (double)cells_owned(c));
   launch_add_force(c->stream, c->g, c->own_r0, c->own_r0 + c->rows, c->prm.dt, c->prm.splat_radius,
@@ -762,6 +799,7 @@ int fluid_read(fluid_ctx *c, int field, void *dst, size_t dst_bytes) {
 
 int fluid_write(fluid_ctx *c, int field, const void *srcv, size_t src_bytes) {
   if (!c || !srcv) return FLUID_E_INVALID;
+  c->advect_early = false;  // rows advected ahead of the step are stale now (recomputed by the full launch)
   if (field == FLUID_VORTICITY) {
     int r = ensure_vort(c);
     if (r) return r;
@@ -920,6 +958,11 @@ int fluid_step_part(fluid_ctx *c, int part) {
       break;
     case FLUID_PART_TAIL_DENSITY_INTERIOR:
       if (!c->tail_edges_done) return fail(c, FLUID_E_INVALID, "FLUID_PART_TAIL_DENSITY_EDGES must run first");
+      break;
+    case FLUID_PART_ADVECT_INTERIOR:  // between two steps of a slab context, once
+      if (!c->slab) return FLUID_E_UNSUPPORTED;
+      if (c->advect_early || c->tail_edges_done || (c->pgroup != 0 && c->pgroup != c->groups))
+        return fail(c, FLUID_E_INVALID, "FLUID_PART_ADVECT_INTERIOR belongs between two steps");
       break;
     default:
       return FLUID_E_INVALID;

@@ -133,6 +133,8 @@ class SlabSim:
         self.P = pkg.PART_PRESSURE_GROUP
         self.groups = self.sim.pressure_groups
         self.split_tail = not (params.get("flags", 0) & pkg.FLAG_UNFUSED)
+        # the interior rows of the next step's advection before its velocity halos are waited for
+        self.early_advect = os.environ.get("FLUID_SLAB_EARLY_ADVECT", "1") != "0"
 
     def _velocity_part(self, tail=True):
         """The velocity part on the compute stream (``tail=False``: without the gradient
@@ -199,6 +201,9 @@ class SlabSim:
             if not self.ex.in_flight(D):
                 self._start(D)
             if self.split_tail:
+                if self.early_advect:
+                    with self.torch.cuda.stream(self.stream):
+                        sim.step_part(self.pkg.PART_ADVECT_INTERIOR)
                 self._finish(V)
                 self._velocity_part(tail=False)
                 self._finish(D)
@@ -274,9 +279,11 @@ class LocalSlabGroup:
     subtraction + density advection in two launches (edge rows, then interior), with the halo
     blocks for the next step packed between the two."""
 
-    def __init__(self, pkg, n: int, count: int, device_index: int = 0, split_tail: bool = False, **params):
+    def __init__(self, pkg, n: int, count: int, device_index: int = 0, split_tail: bool = False,
+                 early_advect: bool = False, **params):
         import torch
         self.pkg, self.count, self.split_tail = pkg, count, split_tail
+        self.early_advect = early_advect   # FLUID_PART_ADVECT_INTERIOR before the velocity halos are unpacked
         self.sims = [pkg.FluidSim(n, device=device_index, slab_rank=r, slab_count=count, **params)
                      for r in range(count)]
         self.groups = self.sims[0].pressure_groups
@@ -326,6 +333,8 @@ class LocalSlabGroup:
             if not self.early_valid:
                 self._pack(V)
                 self._pack(D)
+            if self.early_advect:
+                self._each(pkg.PART_ADVECT_INTERIOR)
             self._unpack(V)
             self._unpack(D)
             self.early_valid = False

@@ -280,7 +280,14 @@ enum {
    * launches over consecutive row ranges (env FLUID_INTERIOR_SPLIT, 1..8) so that work queued on
    * another stream in the meantime is dispatched at a launch boundary at the latest. */
   FLUID_PART_TAIL_DENSITY_EDGES = 32,
-  FLUID_PART_TAIL_DENSITY_INTERIOR = 64
+  FLUID_PART_TAIL_DENSITY_INTERIOR = 64,
+  /* Slab contexts, between two steps: the next step's advection (kernel.cu:114-140) on the same
+   * interior rows, which read no halo row, so it can run before that step's velocity halos have
+   * arrived (more cover for the message); the following VELOCITY / VELOCITY_HEAD then advects only
+   * the rows either side.  Same kernel, inputs and bits.  A backtrace from those rows that leaves
+   * the owned rows (longer than halo_vel rows) is reported as FLUID_E_HALO.  fluid_add_source,
+   * fluid_reset and fluid_write cancel it (the full advection runs). */
+  FLUID_PART_ADVECT_INTERIOR = 128
 };
 FLUID_API int fluid_step_part(fluid_ctx *ctx, int part);
 FLUID_API size_t fluid_halo_bytes_part(const fluid_ctx *ctx, int dir, int parts);

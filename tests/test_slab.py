@@ -158,6 +158,42 @@ def test_interior_of_the_split_tail_in_several_launches(pkg, hip, pieces, monkey
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("split_tail", [True, False], ids=["split", "whole-step"])
+@pytest.mark.parametrize("count,n,D,J,A,G", [(2, 256, 10, 10, 1, 0), (4, 512, 10, 40, 8, 0), (3, 300, 3, 7, 2, 2),
+                                             (8, 1024, 10, 40, 8, 0), (4, 128, 10, 10, 8, 0), (2, 1136, 4, 27, 5, 2)])
+def test_interior_advection_ahead_of_the_halos(pkg, hip, count, n, D, J, A, G, split_tail):
+    """FLUID_PART_ADVECT_INTERIOR: the interior rows of a step's advection run before the step's
+    velocity halos are unpacked (the halo rows still hold the previous step's leftovers), the
+    rest after.  Same bits as the whole domain, also when the band is empty (slab shorter than
+    two halos), with pressure groups, and when a splat or a write cancels it."""
+    import fluid_simulation_amd.slab as slab
+    whole = pkg.FluidSim(n, diffusion_iters=D, pressure_iters=J)
+    group = slab.LocalSlabGroup(pkg, n, count, split_tail=split_tail, early_advect=True, diffusion_iters=D,
+                                pressure_iters=J, halo_rows=A, pressure_groups=G)
+    ss_a, ss_b = pkg.SplatStream(), pkg.SplatStream()
+    for s in range(6):
+        if s % 3 == 0:
+            whole.add_source(*ss_a.splat())
+            group.add_source(*ss_b.splat())
+        if s == 4:   # ahead of a splat: cancelled, the step advects every row itself
+            for sim in group.sims:
+                sim.step_part(pkg.PART_ADVECT_INTERIOR)
+            with pytest.raises(pkg.FluidError):
+                group.sims[0].step_part(pkg.PART_ADVECT_INTERIOR)   # once per step
+            whole.add_source(*ss_a.splat())
+            group.add_source(*ss_b.splat())
+        whole.step(1)
+        group.step(1)
+    for f, fid in (("velocity", pkg.FIELD_VELOCITY), ("density", pkg.FIELD_DENSITY),
+                   ("pressure", pkg.FIELD_PRESSURE), ("divergence", pkg.FIELD_DIVERGENCE)):
+        assert_bit_equal(group.read(fid), whole.read(fid), f"{f} count={count}")
+    with pytest.raises(pkg.FluidError):
+        whole.step_part(pkg.PART_ADVECT_INTERIOR)   # slab contexts only
+    group.close()
+    whole.close()
+
+
+@pytest.mark.gpu
 def test_slabs_long_backtraces_and_halo_violation(pkg, hip):
     """Backtraces of several rows are fine while they stay within halo_rows; one that leaves it
     must be reported (FLUID_E_HALO), never silently wrong."""

@@ -99,8 +99,8 @@ for i in range(nc):
     split = bool(rng.random() < 0.6)
     fl = pkg.FLAG_UNFUSED if rng.random() < 0.2 else 0
     try:
-        grp = slab.LocalSlabGroup(pkg, n, count, split_tail=split and not fl, diffusion_iters=D, pressure_iters=J,
-                                  halo_rows=A, pressure_groups=G, flags=fl)
+        grp = slab.LocalSlabGroup(pkg, n, count, split_tail=split and not fl, early_advect=bool(rng.random() < 0.5),
+                                  diffusion_iters=D, pressure_iters=J, halo_rows=A, pressure_groups=G, flags=fl)
     except pkg.FluidError as e:
         print("skip", n, count, D, J, A, G, e)
         continue
@@ -141,7 +141,8 @@ for i in range(nd):
         if count == 1:
             tst = pkg.FluidSim(n, diffusion_iters=D, pressure_iters=J)
         else:
-            tst = slab.LocalSlabGroup(pkg, n, count, split_tail=bool(rng.random() < 0.5), diffusion_iters=D,
+            tst = slab.LocalSlabGroup(pkg, n, count, split_tail=bool(rng.random() < 0.5),
+                                      early_advect=bool(rng.random() < 0.5), diffusion_iters=D,
                                       pressure_iters=J, halo_rows=A)
     except pkg.FluidError as e:
         print("skip", n, count, D, J, A, env, e)
