@@ -134,7 +134,7 @@ class SlabSim:
         self.groups = self.sim.pressure_groups
         self.split_tail = not (params.get("flags", 0) & pkg.FLAG_UNFUSED)
         # the interior rows of the next step's advection before its velocity halos are waited for
-        self.early_advect = os.environ.get("FLUID_SLAB_EARLY_ADVECT", "1") != "0"
+        self.early_advect = world > 1 and os.environ.get("FLUID_SLAB_EARLY_ADVECT", "1") != "0"
 
     def _velocity_part(self, tail=True):
         """The velocity part on the compute stream (``tail=False``: without the gradient
