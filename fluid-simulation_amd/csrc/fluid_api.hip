@@ -164,12 +164,10 @@ void enq_advect_velocity(fluid_ctx *c, int out_m) {
   const Range r = widened(c, out_m);
   // after FLUID_PART_ADVECT_INTERIOR only the rows on either side of the interior band are left
   const Range band = c->advect_early ? interior_band(c) : Range{r.r1, r.r1};
-  const Range todo[2] = {Range{r.r0, band.r0}, Range{band.r1, r.r1}};
-  for (const Range &t : todo) {
-    if (t.r1 <= t.r0) continue;
-    ProfScope p(c, K_ADVECT_VEL, 16.0 * cells * (t.r1 - t.r0) / (r.r1 - r.r0));
-    launch_advect_vel(c->stream, c->g, t.r0, t.r1, 0, c->g.L, c->prm.dt, c->vel[c->vin],
-                      c->vel[c->vin ^ 1], c->halo_flag, c->nt_stores);
+  {  // [r.r0, band.r0) and [band.r1, r.r1) in one launch; the second range is empty without the band
+    ProfScope p(c, K_ADVECT_VEL, 16.0 * cells * ((band.r0 - r.r0) + (r.r1 - band.r1)) / (r.r1 - r.r0));
+    launch_advect_vel(c->stream, c->g, r.r0, band.r0, 0, c->g.L, c->prm.dt, c->vel[c->vin],
+                      c->vel[c->vin ^ 1], c->halo_flag, c->nt_stores, band.r1, r.r1);
   }
   c->advect_early = false;
   c->vin ^= 1;
@@ -392,28 +390,29 @@ void enq_gradient_density_rows(fluid_ctx *c, bool edges) {
   // EDGES reads the current buffers and writes the other halves, then flips; INTERIOR runs after
   // the flip, so its input is the other half and its output the current one.
   const int vi = edges ? c->vin : c->vin ^ 1, di = edges ? c->din : c->din ^ 1;
-  // The interior goes out as a few launches, not one: work queued on another stream meanwhile (the
-  // halo messages) is sure of a way in at each boundary (a kernel of few, large
-  // workgroups did not get in while one long launch kept every CU refilled).
-  Range parts[8];
-  int np = 0;
-  if (edges) {
-    parts[np++] = Range{own.r0, lo_end};
-    parts[np++] = Range{hi_beg, own.r1};
+  if (edges) {  // both edges in one launch (two launches of ~11 us each are mostly ramp-up and drain)
+    const int rows = (lo_end - own.r0) + (own.r1 - hi_beg);
+    if (rows > 0) {
+      ProfScope p(c, K_PROJECT_ADVECT_DENS, 60.0 * (double)c->g.n * rows);
+      launch_project_advect_dens(c->stream, c->g, own.r0, lo_end, valid.r0, valid.r1, c->prm.dt, c->vel[vi],
+                                 c->prs[c->pin], c->vel[vi ^ 1], c->dens[di], c->dens[di ^ 1], c->halo_flag,
+                                 false, hi_beg, own.r1);  // regular stores: the edge rows are packed next
+    }
   } else {
+    // The interior goes out as a few launches, not one: work queued on another stream meanwhile
+    // (the halo messages) is sure of a way in at each boundary (a kernel of few, large
+    // workgroups did not get in while one long launch kept every CU refilled).
     const int rows = hi_beg - lo_end;
     int k = c->interior_split;
     while (k > 1 && (double)c->g.n * rows / k < (double)c->interior_piece_min) --k;  // keep every piece a full launch
-    for (int i = 0; i < k; ++i)
-      parts[np++] = Range{lo_end + (int)((long)rows * i / k), lo_end + (int)((long)rows * (i + 1) / k)};
-  }
-  for (int i = 0; i < np; ++i) {
-    const Range r = parts[i];
-    if (r.r1 <= r.r0) continue;
-    ProfScope p(c, K_PROJECT_ADVECT_DENS, 60.0 * (double)c->g.n * (r.r1 - r.r0));
-    launch_project_advect_dens(c->stream, c->g, r.r0, r.r1, valid.r0, valid.r1, c->prm.dt,
-                               c->vel[vi], c->prs[c->pin], c->vel[vi ^ 1], c->dens[di],
-                               c->dens[di ^ 1], c->halo_flag, c->nt_stores && !edges);  // edge rows are packed next
+    for (int i = 0; i < k; ++i) {
+      const Range r{lo_end + (int)((long)rows * i / k), lo_end + (int)((long)rows * (i + 1) / k)};
+      if (r.r1 <= r.r0) continue;
+      ProfScope p(c, K_PROJECT_ADVECT_DENS, 60.0 * (double)c->g.n * (r.r1 - r.r0));
+      launch_project_advect_dens(c->stream, c->g, r.r0, r.r1, valid.r0, valid.r1, c->prm.dt, c->vel[vi],
+                                 c->prs[c->pin], c->vel[vi ^ 1], c->dens[di], c->dens[di ^ 1], c->halo_flag,
+                                 c->nt_stores);
+    }
   }
   if (edges) {
     c->vin ^= 1;

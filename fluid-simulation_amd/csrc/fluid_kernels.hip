@@ -65,6 +65,7 @@ __device__ __forceinline__ float4 mix(float4 x, float4 y, float a) {
 // A row outside the stored rows raises *flag (advection left the halo) and is
 // clamped so the access stays in bounds.
 struct Valid { int lo, hi; };  // local rows [lo, hi) that hold current data
+struct Rows { int r0, r1; };   // a second row range for the blocks with blockIdx.z == 1
 
 template <typename T>
 __device__ __forceinline__ T texel(const T *t, Geom g, int i, int j, Valid v, int *flag) {
@@ -146,10 +147,11 @@ constexpr int ADV_ROWS_DENS = ADV_RD;  // float4 texels: more rows cost occupanc
 
 // kernel.cu:114-140
 template <bool NT>
-__global__ __launch_bounds__(BX *BY) void k_advect_vel(Geom g, int r0, int r1, Valid valid, float dt,
+__global__ __launch_bounds__(BX *BY) void k_advect_vel(Geom g, int r0, int r1, Rows second, Valid valid, float dt,
                                                         const float2 *__restrict__ vin,
                                                         float2 *__restrict__ vout, int *flag) {
   constexpr int ADV_ROWS = ADV_ROWS_VEL;
+  if (blockIdx.z) { r0 = second.r0; r1 = second.r1; }  // two row ranges in one launch (slab edges)
   ADVECT_PROLOGUE
   float2 v[ADV_ROWS];
 #pragma unroll
@@ -335,9 +337,10 @@ __global__ __launch_bounds__(BX *BY) void k_project(Geom g, int r0, int r1,
 constexpr int TAIL_BY = FUSED_BY;  // rows per block of the fused kernel
 template <bool NT>
 __global__ __launch_bounds__(BX *TAIL_BY) void k_project_advect_dens(
-    Geom g, int r0, int r1, Valid valid, float dt, const float2 *__restrict__ vin,
+    Geom g, int r0, int r1, Rows second, Valid valid, float dt, const float2 *__restrict__ vin,
     const float *__restrict__ p, float2 *__restrict__ vout, const float4 *__restrict__ din,
     float4 *__restrict__ dout, int *flag) {
+  if (blockIdx.z) { r0 = second.r0; r1 = second.r1; }  // two row ranges in one launch (slab edges)
   const int x = blockIdx.x * BX + threadIdx.x;
   const int r = r0 + blockIdx.y * TAIL_BY + threadIdx.y;
   if (x >= g.n || r >= r1) return;
@@ -438,15 +441,25 @@ void launch_copy_block(hipStream_t s, void *dst, const void *src, size_t bytes) 
                        (const unsigned *)src, (unsigned *)dst, count);
   }
 }
+// r0b..r1b: an optional second row range handled by the same launch (the two edges of a slab:
+// two launches of ~10 us each are mostly ramp-up and drain).
 void launch_advect_vel(hipStream_t s, Geom g, int r0, int r1, int vlo, int vhi, float dt,
-                       const float2 *vin, float2 *vout, int *flag, bool nt) {
+                       const float2 *vin, float2 *vout, int *flag, bool nt, int r0b, int r1b) {
+  if (r1 <= r0) { r0 = r0b; r1 = r1b; r0b = r1b = 0; }
   if (r1 <= r0) return;
+  const bool two = r1b > r0b;
+  dim3 grid = grid_adv(g, r0, r1, ADV_ROWS_VEL);
+  if (two) {
+    const dim3 gb = grid_adv(g, r0b, r1b, ADV_ROWS_VEL);
+    grid.y = grid.y > gb.y ? grid.y : gb.y;
+    grid.z = 2;
+  }
   if (nt)
-    hipLaunchKernelGGL(k_advect_vel<true>, grid_adv(g, r0, r1, ADV_ROWS_VEL), kBlock, 0, s, g, r0, r1,
-                       Valid{vlo, vhi}, dt, vin, vout, flag);
+    hipLaunchKernelGGL(k_advect_vel<true>, grid, kBlock, 0, s, g, r0, r1, Rows{r0b, r1b}, Valid{vlo, vhi}, dt, vin,
+                       vout, flag);
   else
-    hipLaunchKernelGGL(k_advect_vel<false>, grid_adv(g, r0, r1, ADV_ROWS_VEL), kBlock, 0, s, g, r0, r1,
-                       Valid{vlo, vhi}, dt, vin, vout, flag);
+    hipLaunchKernelGGL(k_advect_vel<false>, grid, kBlock, 0, s, g, r0, r1, Rows{r0b, r1b}, Valid{vlo, vhi}, dt, vin,
+                       vout, flag);
 }
 void launch_diffuse(hipStream_t s, Geom g, int r0, int r1, float alpha, float beta,
                     const float2 *vin, float2 *vout) {
@@ -469,15 +482,17 @@ void launch_project(hipStream_t s, Geom g, int r0, int r1, const float2 *vin, co
 }
 void launch_project_advect_dens(hipStream_t s, Geom g, int r0, int r1, int vlo, int vhi, float dt,
                                 const float2 *vin, const float *p, float2 *vout, const float4 *din,
-                                float4 *dout, int *flag, bool nt) {
+                                float4 *dout, int *flag, bool nt, int r0b, int r1b) {
+  if (r1 <= r0) { r0 = r0b; r1 = r1b; r0b = r1b = 0; }
   if (r1 <= r0) return;
-  const dim3 grid((g.n + BX - 1) / BX, (r1 - r0 + TAIL_BY - 1) / TAIL_BY), block(BX, TAIL_BY);
+  const int rows = r1b - r0b > r1 - r0 ? r1b - r0b : r1 - r0;
+  const dim3 grid((g.n + BX - 1) / BX, (rows + TAIL_BY - 1) / TAIL_BY, r1b > r0b ? 2 : 1), block(BX, TAIL_BY);
   if (nt)
-    hipLaunchKernelGGL(k_project_advect_dens<true>, grid, block, 0, s, g, r0, r1, Valid{vlo, vhi}, dt, vin, p,
-                       vout, din, dout, flag);
+    hipLaunchKernelGGL(k_project_advect_dens<true>, grid, block, 0, s, g, r0, r1, Rows{r0b, r1b}, Valid{vlo, vhi}, dt,
+                       vin, p, vout, din, dout, flag);
   else
-    hipLaunchKernelGGL(k_project_advect_dens<false>, grid, block, 0, s, g, r0, r1, Valid{vlo, vhi}, dt, vin, p,
-                       vout, din, dout, flag);
+    hipLaunchKernelGGL(k_project_advect_dens<false>, grid, block, 0, s, g, r0, r1, Rows{r0b, r1b}, Valid{vlo, vhi}, dt,
+                       vin, p, vout, din, dout, flag);
 }
 void launch_advect_dens(hipStream_t s, Geom g, int r0, int r1, int vlo, int vhi, float dt,
                         const float2 *vel, const float4 *din, float4 *dout, int *flag) {
