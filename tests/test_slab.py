@@ -194,16 +194,18 @@ def test_interior_advection_ahead_of_the_halos(pkg, hip, count, n, D, J, A, G, s
 
 
 @pytest.mark.gpu
-def test_slabs_long_backtraces_and_halo_violation(pkg, hip):
+@pytest.mark.parametrize("early", [False, True], ids=["plain", "early-advect"])
+def test_slabs_long_backtraces_and_halo_violation(pkg, hip, early):
     """Backtraces of several rows are fine while they stay within halo_rows; one that leaves it
-    must be reported (FLUID_E_HALO), never silently wrong."""
+    must be reported (FLUID_E_HALO), never silently wrong — also when the interior rows are
+    advected ahead of the halos (FLUID_PART_ADVECT_INTERIOR)."""
     import fluid_simulation_amd.slab as slab
     n, count = 512, 4
     vel, dens, _ = random_state(n, seed=5, vmax=60.0)  # dt*v up to 6 rows
     whole = pkg.FluidSim(n)
     whole.write(pkg.FIELD_VELOCITY, vel)
     whole.write(pkg.FIELD_DENSITY, dens)
-    group = slab.LocalSlabGroup(pkg, n, count, halo_rows=8)
+    group = slab.LocalSlabGroup(pkg, n, count, halo_rows=8, early_advect=early)
     group.write(pkg.FIELD_VELOCITY, vel)
     group.write(pkg.FIELD_DENSITY, dens)
     whole.step(1)
@@ -212,7 +214,7 @@ def test_slabs_long_backtraces_and_halo_violation(pkg, hip):
     assert_bit_equal(group.read(pkg.FIELD_DENSITY), whole.read(pkg.FIELD_DENSITY), "density")
     group.close()
     # halo_rows = 2 is too shallow for 6-row backtraces
-    group = slab.LocalSlabGroup(pkg, n, count, halo_rows=2)
+    group = slab.LocalSlabGroup(pkg, n, count, halo_rows=2, early_advect=early)
     group.write(pkg.FIELD_VELOCITY, vel)
     group.write(pkg.FIELD_DENSITY, dens)
     with pytest.raises(pkg.FluidError) as ei:
