@@ -108,6 +108,7 @@ def run_multi(pkg, args, n, D, J, flags):
             "transport": "RCCL (torch.distributed nccl)" if backend == "nccl" else backend,
             "halo_bytes_per_step_per_rank": sim.ex.bytes_moved // max(args.steps + args.warmup, 1),
             "overlap": sim.overlap, "overlap_matches_plain_exchange": overlap_ok,
+            "early_interior_advection": bool(sim.overlap and sim.split_tail and sim.early_advect),
             "diagnostics_after_run": diag,
         }
         print(json.dumps(out), flush=True)
