@@ -69,6 +69,27 @@ def run_multi(pkg, args, n, D, J, flags):
     sim = SlabSim(pkg, n, rank=rank, world=world, device_index=local, diffusion_iters=D,
                   pressure_iters=J, flags=flags, overlap=None if overlap_ok else False, **gkw)
     seeded_warm_state(pkg, sim)          # every rank applies the same splats to its own rows
+    # The early interior advection (FLUID_PART_ADVECT_INTERIOR) buys the velocity message 0.1 ms more
+    # cover for 12 us of launches per step; which way that nets out depends on the links of the node
+    # at hand, so both ways are tried on the real transport, before the warm-up and the timed region.
+    # Every rank takes the same decision (times are max-reduced over the ranks).
+    tune = None
+    if sim.overlap and sim.split_tail and sim.early_advect and os.environ.get("FLUID_SLAB_EARLY_ADVECT") is None:
+        tune, trial = {}, (20 if backend == "nccl" else 2)
+        for early in (True, False):
+            sim.early_advect = early
+            sim.step(3)
+            sim.sync()
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            sim.step(trial)
+            sim.sync()
+            torch.cuda.synchronize()
+            tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            tune["early" if early else "late"] = round(float(tt.item()) / trial * 1e3, 5)
+        sim.early_advect = tune["early"] <= tune["late"]
     sim.step(args.warmup)
     sim.sync()
     torch.cuda.synchronize()
@@ -109,6 +130,7 @@ def run_multi(pkg, args, n, D, J, flags):
             "halo_bytes_per_step_per_rank": sim.ex.bytes_moved // max(args.steps + args.warmup, 1),
             "overlap": sim.overlap, "overlap_matches_plain_exchange": overlap_ok,
             "early_interior_advection": bool(sim.overlap and sim.split_tail and sim.early_advect),
+            "early_interior_advection_trial_ms_per_step": tune,
             "diagnostics_after_run": diag,
         }
         print(json.dumps(out), flush=True)
