@@ -7,9 +7,13 @@ One "step" = one full simulationStep() (kernel.cu:701-708) over the whole grid. 
 cell-updates/s per full timestep (GCUPS = n^2 / t_step / 1e9) and the HBM-roofline fraction
 (BASELINE.json).  Prints ONE JSON line on rank 0.
 
-For N > 1 the driver launches this file under torch.distributed.run, one rank per GPU; the grid
-is cut into N row slabs (strong scaling: the total grid is fixed) and halo rows travel over
-RCCL (torch.distributed backend "nccl").
+For N > 1 there is one rank per GPU; the grid is cut into N row slabs (strong scaling: the total
+grid is fixed) and halo rows travel over RCCL.  Two ways in:
+  - under a launcher (torch.distributed.run sets RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*): this
+    process is one rank;
+  - plain `python bench.py --gpus N`: this process touches no GPU, starts N fresh children of
+    itself with those variables set (launch_ranks), relays rank 0's JSON line, and exits non-zero
+    if a rank fails or the wall-clock limit (FLUID_BENCH_TIMEOUT, seconds) passes.
 """
 import argparse
 import json
@@ -94,36 +98,145 @@ def cpu_baseline(pkg, D, J, budget_s=12.0, threads=1):
     }
 
 
-def roofline_from_profile(sim, steps, workload):
+def load_pmc(workload):
+    """profiles/pmc_traffic.json: HBM bytes per launch from rocprofv3 PMC passes (2*FETCH_SIZE +
+    WRITE_SIZE, KiB -> bytes: MI355X_MICROARCH.md's gfx950 correction), written by
+    tools/summarize_profile.py from a run of THIS file on the GPU box.  Counters cannot be
+    collected inside an ordinary bench run, so the table is replayed here, stamped with the
+    commit, date and workload it was collected on; None when it is for another workload."""
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        pmc = json.load(open(pmc_path))
+    except Exception:
+        return None
+    return pmc if pmc.get("_workload") == workload else None
+
+
+def roofline_from_profile(sim, steps, workload, t_step):
     stats = sim.profile_steps(steps)
+    pmc = load_pmc(workload)
     dom = max(stats, key=lambda s: s["total_ms"])
     avg_ms = dom["total_ms"] / dom["launches"]
     achieved = dom["alg_bytes"] / (avg_ms * 1e-3) / 1e9
-    per_kernel = {s["name"]: {"launches_per_step": s["launches"] / steps,
-                              "avg_ms": round(s["total_ms"] / s["launches"], 5),
-                              "alg_GBps": round(s["alg_bytes"] / (s["total_ms"] / s["launches"] * 1e-3) / 1e9, 1)}
-                  for s in stats}
-    traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc_path):
-        try:
-            pmc = json.load(open(pmc_path))
-            if pmc.get("_workload") == workload:  # counters are per launch of THAT workload's kernels
-                traffic = pmc.get(dom["name"], {}).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
-    # `achieved` prices every sweep's algorithmic bytes (contract), so a temporally blocked
-    # launch of K sweeps can exceed the HBM peak; `traffic_frac` is the bytes the PMC counters
-    # saw actually crossing HBM over the same launch duration.
+    moved_rate = dom["moved_bytes"] / (avg_ms * 1e-3) / 1e9
+    per_kernel, step_moved, step_traffic, step_kernel_ms = {}, 0.0, 0.0, 0.0
+    for s in stats:
+        a_ms = s["total_ms"] / s["launches"]
+        tr = pmc.get(s["name"], {}).get("hbm_bytes_per_launch") if pmc else None
+        per_kernel[s["name"]] = {
+            "launches_per_step": s["launches"] / steps, "avg_ms": round(a_ms, 5),
+            "alg_GBps": round(s["alg_bytes"] / (a_ms * 1e-3) / 1e9, 1),
+            "moved_GBps": round(s["moved_bytes"] / (a_ms * 1e-3) / 1e9, 1),
+            "traffic_GBps": round(tr / (a_ms * 1e-3) / 1e9, 1) if tr else None}
+        step_moved += s["moved_bytes"] * s["launches"] / steps
+        step_kernel_ms += s["total_ms"] / steps
+        if tr is not None and step_traffic is not None:
+            step_traffic += tr * s["launches"] / steps
+        else:
+            step_traffic = None
+    traffic = pmc.get(dom["name"], {}).get("hbm_bytes_per_launch") if pmc else None
+    # `achieved`/`frac` price every reference launch's algorithmic bytes (the contract, SURVEY.md
+    # 8d), so a launch that fuses reference launches is credited bytes that never cross HBM:
+    # `frac_moved` prices only what the launch itself must move, `traffic_frac` what the PMC
+    # counters saw crossing HBM, both over the same launch duration.
     moved = traffic / (avg_ms * 1e-3) / 1e9 if traffic else None
-    return {
+    roof = {
         "bound": "hbm", "kernel": dom["name"], "achieved": round(achieved, 1),
         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
         "traffic": traffic, "avg_launch_ms": round(avg_ms, 5),
         "alg_bytes_per_launch": dom["alg_bytes"],
+        "moved_bytes_per_launch": dom["moved_bytes"],
+        "frac_moved": round(moved_rate / HBM_PEAK_GBPS, 4),
         "traffic_GBps": round(moved, 1) if moved else None,
         "traffic_frac": round(moved / HBM_PEAK_GBPS, 4) if moved else None,
-    }, per_kernel
+        "traffic_collected": ({"commit": pmc.get("_commit"), "date": pmc.get("_date"), "workload": pmc.get("_workload"),
+                               "source": pmc.get("_source"), "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                               "bench.py on an MI355X; replayed, not measured in this run"} if pmc else None),
+    }
+    # Step level, honest version: the launches actually issued move `step_moved_bytes` (compulsory)
+    # and `step_traffic_bytes` (counters) per step; over the wall-clock step time.
+    step = {
+        "step_moved_bytes": step_moved,
+        "step_moved_bytes_per_cell": round(step_moved / (sim.n * sim.n), 2),
+        "step_moved_frac": round(step_moved / t_step / 1e9 / HBM_PEAK_GBPS, 4),
+        "step_traffic_bytes": step_traffic,
+        "step_traffic_frac": round(step_traffic / t_step / 1e9 / HBM_PEAK_GBPS, 4) if step_traffic else None,
+        "step_kernel_ms_sum": round(step_kernel_ms, 5),
+    }
+    return roof, per_kernel, step
+
+
+def cpu_baseline_config0(pkg):
+    """BASELINE.json configs[0] verbatim (SURVEY.md 8d "Config -> run (1)"): the serial host-C
+    transcription, 512^2, D = J = 10, 100 steps on the seeded splat script, one core."""
+    lib = pkg.FluidLib(os.path.join(ROOT, "oracle", "liboracle_fluid.so"))
+    n, steps = 512, 100
+    sim = pkg.FluidSim(n, diffusion_iters=10, pressure_iters=10, lib=lib)
+    t0 = time.perf_counter()
+    pkg.run_seeded(sim, steps)
+    el = time.perf_counter() - t0
+    return {"value": round(n * n * steps / el / 1e9, 6), "unit": "GCUPS", "cores": 1, "kind": "port",
+            "ms_per_step": round(el / steps * 1e3, 3),
+            "sample": f"{n}x{n} grid, D=10, J=10, {steps} steps, seeded splats every 10th step, serial C oracle "
+                      f"(gcc -O2 -ffp-contract=off), {el:.1f} s"}
+
+
+def launch_ranks(nranks, argv):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes of this file.
+
+    The parent never imports torch or touches HIP (a process that has initialised the GPU must not
+    be re-executed, and it would hold a context the ranks do not need).  Every rank gets RANK /
+    LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT (a port found free just now) and
+    its own session, so that the whole group can be ended by process-group id.  Rank 0's stdout is
+    this process's stdout; the other ranks' output goes to stderr.  Returns the exit code."""
+    import signal
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    limit = float(os.environ.get("FLUID_BENCH_TIMEOUT", "1500"))
+    procs = []
+    for r in range(nranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nranks), LOCAL_WORLD_SIZE=str(nranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FLUID_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else sys.stderr, start_new_session=True))
+
+    def end_all():
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)   # the rank's own session: exactly what was started here
+                except ProcessLookupError:
+                    pass
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                pass
+
+    t0, rc = time.monotonic(), 0
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                print(f"bench.py: rank {bad[0][0]} exited with {bad[0][1]}; ending the other ranks", file=sys.stderr)
+                rc = 1
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.monotonic() - t0 > limit:
+                print(f"bench.py: {nranks} ranks not done after {limit:.0f} s (FLUID_BENCH_TIMEOUT); ending them",
+                      file=sys.stderr)
+                rc = 124
+                break
+            time.sleep(0.05)
+    finally:
+        end_all()
+    return rc
 
 
 def main():
@@ -136,6 +249,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra single-GPU workloads")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))   # before anything imports torch / touches HIP
 
     import fluid_amd_loader
     pkg = fluid_amd_loader.load()
@@ -152,7 +268,7 @@ def main():
     bpc = pkg.alg_bytes_per_cell(D, J)
     gcups = n * n / t_step / 1e9
     ev_ms = sim.time_steps(args.steps) / args.steps
-    roof, per_kernel = roofline_from_profile(sim, max(2, min(args.steps, 5)), args.workload)
+    roof, per_kernel, step_acct = roofline_from_profile(sim, max(2, min(args.steps, 5)), args.workload, t_step)
     diag = sim.diagnostics()   # state after the run (wavefront reductions; outside the timed region)
     sim.close()
 
@@ -168,6 +284,7 @@ def main():
         "step_effective_GBps": round(bpc * n * n / t_step / 1e9, 1),
         "step_frac_of_hbm_peak": round(bpc * n * n / t_step / 1e9 / HBM_PEAK_GBPS, 4),
         "hip_event_ms_per_step": round(ev_ms, 5),
+        **step_acct,
         "roofline": roof,
         "kernels": per_kernel,
         "diagnostics_after_run": diag,
@@ -188,6 +305,7 @@ def main():
         out["other_workloads"] = extra
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(pkg, D, J)
+        out["cpu_baseline_config0"] = cpu_baseline_config0(pkg)
         nthr = cpu_threads()
         if nthr > 1 and os.path.exists(os.path.join(ROOT, "oracle", "liboracle_fluid_omp.so")):
             out["cpu_baseline_parallel"] = cpu_baseline(pkg, D, J, budget_s=6.0, threads=nthr)

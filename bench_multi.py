@@ -23,18 +23,19 @@ def run_multi(pkg, args, n, D, J, flags):
     if os.environ.get("FLUID_BENCH_ONE_GPU"):
         local = 0
     torch.cuda.set_device(local)
+    # A rank that waits for a peer that never comes (or a transfer that never ends) must not hang
+    # the job: after FLUID_BENCH_RANK_TIMEOUT seconds every rank dumps its Python stacks and exits
+    # non-zero (the launcher in bench.py / torch.distributed.run then ends the others).
+    import datetime
+    import faulthandler
+    limit = float(os.environ.get("FLUID_BENCH_RANK_TIMEOUT", "1200"))
+    faulthandler.dump_traceback_later(limit, exit=True)
+    tmo = datetime.timedelta(seconds=min(limit, 600))
     if backend == "nccl":
-        kw = {}
-        if os.environ.get("FLUID_SLAB_HIGH_PRIORITY", "0") == "1":  # see SlabSim.comm_stream: off by default
-            try:
-                opts = dist.ProcessGroupNCCL.Options()
-                opts.is_high_priority_stream = True
-                kw["pg_options"] = opts
-            except Exception:
-                pass
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local), **kw)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local),
+                                timeout=tmo)
     else:
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world, timeout=tmo)
 
     # Deep pressure loops on short slabs: the J sweeps can be cut into groups with a pressure-halo
     # exchange in between (include/fluid.h, pressure_groups).  Measured on one MI355X (tools/
@@ -94,12 +95,14 @@ def run_multi(pkg, args, n, D, J, flags):
     sim.sync()
     torch.cuda.synchronize()
     dist.barrier()
+    moved0 = sim.ex.bytes_moved
     t0 = time.perf_counter()
     sim.step(args.steps)
     sim.sync()
     torch.cuda.synchronize()
     dist.barrier()
     wall = time.perf_counter() - t0
+    moved = sim.ex.bytes_moved - moved0   # sent in the timed region only (the tuning trials above moved more)
     t = torch.tensor([wall], dtype=torch.float64, device="cuda")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall = float(t.item())
@@ -127,7 +130,7 @@ def run_multi(pkg, args, n, D, J, flags):
             "step_effective_GBps": round(bpc * n * n / t_step / 1e9, 1),
             "step_frac_of_hbm_peak": round(bpc * n * n / t_step / 1e9 / (HBM_PEAK_GBPS * world), 4),
             "transport": "RCCL (torch.distributed nccl)" if backend == "nccl" else backend,
-            "halo_bytes_per_step_per_rank": sim.ex.bytes_moved // max(args.steps + args.warmup, 1),
+            "halo_bytes_per_step_per_rank": moved // max(args.steps, 1),
             "overlap": sim.overlap, "overlap_matches_plain_exchange": overlap_ok,
             "early_interior_advection": bool(sim.overlap and sim.split_tail and sim.early_advect),
             "early_interior_advection_trial_ms_per_step": tune,
@@ -137,3 +140,4 @@ def run_multi(pkg, args, n, D, J, flags):
     sim.close()
     dist.barrier()
     dist.destroy_process_group()
+    faulthandler.cancel_dump_traceback_later()

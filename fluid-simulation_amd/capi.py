@@ -53,7 +53,7 @@ class SlabInfo(C.Structure):
 
 class KernelStat(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_int), ("total_ms", C.c_float),
-                ("alg_bytes", C.c_double)]
+                ("alg_bytes", C.c_double), ("moved_bytes", C.c_double)]
 
 
 class FluidDiag(C.Structure):
@@ -321,7 +321,8 @@ class FluidSim:
         self._chk(self.lib.dll.fluid_profile_steps(self._h, nsteps, stats, 32, C.byref(cnt)),
                   "fluid_profile_steps")
         return [dict(name=stats[i].name.decode(), launches=stats[i].launches,
-                     total_ms=stats[i].total_ms, alg_bytes=stats[i].alg_bytes)
+                     total_ms=stats[i].total_ms, alg_bytes=stats[i].alg_bytes,
+                     moved_bytes=stats[i].moved_bytes)
                 for i in range(cnt.value)]
 
     # -- slab halos -----------------------------------------------------------------

@@ -27,7 +27,8 @@ struct GraphEntry {
 struct ProfRec {
   int kid;
   int e0, e1;
-  double bytes;
+  double bytes;  // algorithmic bytes of the reference launches this launch stands for
+  double moved;  // bytes the launch itself has to move: every input once, every output once
 };
 
 }  // namespace
@@ -62,9 +63,13 @@ struct fluid_ctx {
   bool tile = false;  // small grids: LDS-tiled sweeps (fluid_kernels_tile.hip) instead of the register pipeline
   bool nt_stores = false;  // grids far beyond the caches: non-temporal stores in the two streaming kernels
   int graph_steps = 1;     // whole steps captured per graph (fluid_step)
+  int force_k = 0;           // FLUID_TEST_FORCE_K, see next_pass
+  std::vector<int> pass_d, pass_j;  // sweeps of the next launch when `left` diffusion / pressure sweeps remain
+  bool direct_parts = true;  // step parts of one or two kernels are launched directly, not as graphs (FLUID_DIRECT_PARTS)
   int interior_split = 4;  // launches FLUID_PART_TAIL_DENSITY_INTERIOR is cut into (at most)
   int interior_piece_min = 1 << 21;  // ... each of at least this many cells
   bool prof = false;
+  int enq_rc = 0;          // first failure while enqueueing (a launch_* that refused, a failed memset); see check_launch
   std::vector<hipEvent_t> ev_pool;
   size_t ev_used = 0;
   std::vector<ProfRec> recs;
@@ -89,6 +94,23 @@ int fail(fluid_ctx *c, int code, const char *fmt, ...) {
     if (e_ != hipSuccess)                                                                \
       return fail((c), e_ == hipErrorOutOfMemory ? FLUID_E_NOMEM : FLUID_E_DEVICE,       \
                   "%s: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__);   \
+  } while (0)
+
+// The enq_* functions below are void (they also run under stream capture, where a launch cannot
+// be undone); the first thing that goes wrong is kept in c->enq_rc and returned by check_launch
+// after the enqueue, so that no caller ever sees FLUID_OK for a step that was not fully enqueued.
+// launch_*_tb / launch_*_tile return false for a shape or sweep count this build does not hold.
+#define LAUNCH(c, call)                                                                              \
+  do {                                                                                               \
+    if (!(call) && !(c)->enq_rc)                                                                      \
+      (c)->enq_rc = fail((c), FLUID_E_UNSUPPORTED, "%s refused (shape or sweep count not in this build; %s:%d)", \
+                         #call, __FILE__, __LINE__);                                                 \
+  } while (0)
+#define HIPNOTE(c, call)                                                                             \
+  do {                                                                                               \
+    hipError_t e_ = (call);                                                                          \
+    if (e_ != hipSuccess && !(c)->enq_rc)                                                             \
+      (c)->enq_rc = fail((c), FLUID_E_DEVICE, "%s: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
   } while (0)
 
 inline size_t cells_local(const fluid_ctx *c) { return (size_t)c->g.L * c->g.n; }
@@ -116,8 +138,10 @@ int prof_event(fluid_ctx *c) {
 struct ProfScope {
   fluid_ctx *c;
   int kid, e0 = -1;
-  double bytes;
-  ProfScope(fluid_ctx *c_, int kid_, double bytes_) : c(c_), kid(kid_), bytes(bytes_) {
+  double bytes, moved;
+  // moved_ < 0: the launch is one reference launch, its compulsory bytes are the algorithmic ones
+  ProfScope(fluid_ctx *c_, int kid_, double bytes_, double moved_ = -1.0)
+      : c(c_), kid(kid_), bytes(bytes_), moved(moved_ < 0 ? bytes_ : moved_) {
     if (c->prof) {
       e0 = prof_event(c);
       if (e0 >= 0) (void)hipEventRecord(c->ev_pool[e0], c->stream);
@@ -128,7 +152,7 @@ struct ProfScope {
       int e1 = prof_event(c);
       if (e1 >= 0) {
         (void)hipEventRecord(c->ev_pool[e1], c->stream);
-        c->recs.push_back({kid, e0, e1, bytes});
+        c->recs.push_back({kid, e0, e1, bytes, moved});
       }
     }
   }
@@ -194,7 +218,7 @@ int env_int(const char *name, int dflt) {
 // Next launch's sweep count: split `left` sweeps into the fewest launches the instantiated
 // counts (fluid_kernels_tb.hip tb_has_k) allow with none above kmax, and among those the most
 // even split (40 with kmax 14 -> 14 + 13 + 13, not 14 + 14 + 10 + 2).
-int next_pass(int left, int kmax, int cols, bool float2_field, bool tile = false) {
+int plan_pass(int left, int kmax, int cols, bool float2_field, bool tile) {
   if (left <= 1) return 1;
   std::vector<int> cnt(left + 1, 1 << 20), big(left + 1, 0), pick(left + 1, 1);
   cnt[0] = 0;
@@ -208,6 +232,21 @@ int next_pass(int left, int kmax, int cols, bool float2_field, bool tile = false
   int best = pick[left];
   for (int j = left; j > 0; j -= pick[j]) best = pick[j] > best ? pick[j] : best;
   return best;
+}
+
+// The same, from the tables fluid_init fills for this context's plan (pass_d / pass_j: the answer
+// for every `left` up to D / J): enqueueing a step does no planning and no host allocation.
+int next_pass(const fluid_ctx *c, int left, bool float2_field) {
+  // FLUID_TEST_FORCE_K (tests only): every pass asks for this sweep count, instantiated or not
+  if (c->force_k > 0) return c->force_k < left ? c->force_k : left;
+  const std::vector<int> &t = float2_field ? c->pass_d : c->pass_j;
+  return left >= 0 && (size_t)left < t.size() ? t[left] : 1;
+}
+void fill_pass_tables(fluid_ctx *c) {
+  c->pass_d.assign(c->prm.diffusion_iters + 1, 1);
+  c->pass_j.assign(c->prm.pressure_iters + 1, 1);
+  for (int l = 1; l <= c->prm.diffusion_iters; ++l) c->pass_d[l] = plan_pass(l, c->tb_kd, c->tile ? 0 : c->tb_cd, true, c->tile);
+  for (int l = 1; l <= c->prm.pressure_iters; ++l) c->pass_j[l] = plan_pass(l, c->tb_kj, c->tile ? 0 : c->tb_cj, false, c->tile);
 }
 
 // Rows per wave so that the launch has about tb_waves waves.
@@ -231,10 +270,10 @@ void enq_diffuse(fluid_ctx *c, int out_m) {
   const double cells = (double)cells_owned(c);
   if (c->tile && !(c->prm.flags & FLUID_FLAG_UNFUSED)) {
     for (int left = c->prm.diffusion_iters; left > 0;) {
-      const int k = next_pass(left, c->tb_kd, 0, true, true);
-      ProfScope p(c, K_DIFFUSE_TILE, 16.0 * k * cells);
+      const int k = next_pass(c, left, true);
+      ProfScope p(c, K_DIFFUSE_TILE, 16.0 * k * cells, 16.0 * cells);
       const Range r = widened(c, out_m + left - k);
-      launch_diffuse_tile(c->stream, c->g, r.r0, r.r1, k, c->alpha, c->beta, c->vel[c->vin], c->vel[c->vin ^ 1]);
+      LAUNCH(c, launch_diffuse_tile(c->stream, c->g, r.r0, r.r1, k, c->alpha, c->beta, c->vel[c->vin], c->vel[c->vin ^ 1]));
       c->vin ^= 1;
       left -= k;
     }
@@ -242,12 +281,12 @@ void enq_diffuse(fluid_ctx *c, int out_m) {
   }
   if (use_tb(c, c->tb_cd)) {
     for (int left = c->prm.diffusion_iters; left > 0;) {
-      const int k = next_pass(left, c->tb_kd, c->tb_cd, true);
-      ProfScope p(c, K_DIFFUSE_TB, 16.0 * k * cells);
+      const int k = next_pass(c, left, true);
+      ProfScope p(c, K_DIFFUSE_TB, 16.0 * k * cells, 16.0 * cells);
       const Range r = widened(c, out_m + left - k);
-      launch_diffuse_tb(c->stream, c->g, r.r0, r.r1, k, c->tb_cd,
-                        tb_chunk(c, k, c->tb_cd, r.r1 - r.r0), c->alpha, c->beta, c->vel[c->vin],
-                        c->vel[c->vin ^ 1], c->dump);
+      LAUNCH(c, launch_diffuse_tb(c->stream, c->g, r.r0, r.r1, k, c->tb_cd,
+                               tb_chunk(c, k, c->tb_cd, r.r1 - r.r0), c->alpha, c->beta, c->vel[c->vin],
+                               c->vel[c->vin ^ 1], c->dump));
       c->vin ^= 1;
       left -= k;
     }
@@ -295,15 +334,15 @@ void enq_pressure_group(fluid_ctx *c, int g) {
     const int div_m = c->groups > 1 ? glen : -1;
     bool first = g == 0;
     while (left > 0) {
-      const int k = next_pass(left, c->tb_kj, 0, false, true);
+      const int k = next_pass(c, left, false);
       if (first) {
-        ProfScope p(c, K_JACOBI_DIV_TILE, 12.0 * cells + 12.0 * k * cells);
+        ProfScope p(c, K_JACOBI_DIV_TILE, 12.0 * cells + 12.0 * k * cells, 16.0 * cells);  // velocity in, divergence and p out
         const Range r = widened(c, div_m >= 0 ? div_m : 1 + left - k);
-        launch_jacobi_div_tile(c->stream, c->g, r.r0, r.r1, k, c->vel[c->vin], c->div, c->prs[c->pin ^ 1]);
+        LAUNCH(c, launch_jacobi_div_tile(c->stream, c->g, r.r0, r.r1, k, c->vel[c->vin], c->div, c->prs[c->pin ^ 1]));
       } else {
-        ProfScope p(c, K_JACOBI_TILE, 12.0 * k * cells);
+        ProfScope p(c, K_JACOBI_TILE, 12.0 * k * cells, 12.0 * cells);
         const Range r = widened(c, 1 + left - k);
-        launch_jacobi_tile(c->stream, c->g, r.r0, r.r1, k, c->prs[c->pin], c->div, c->prs[c->pin ^ 1]);
+        LAUNCH(c, launch_jacobi_tile(c->stream, c->g, r.r0, r.r1, k, c->prs[c->pin], c->div, c->prs[c->pin ^ 1]));
       }
       first = false;
       c->pin ^= 1;
@@ -313,7 +352,7 @@ void enq_pressure_group(fluid_ctx *c, int g) {
       ProfScope p(c, K_DIVERGENCE, 12.0 * cells);
       const Range r = widened(c, div_m >= 0 ? div_m : J);
       launch_divergence(c->stream, c->g, r.r0, r.r1, c->vel[c->vin], c->div);
-      (void)hipMemsetAsync(c->prs[c->pin], 0, cells_local(c) * sizeof(float), c->stream);
+      HIPNOTE(c, hipMemsetAsync(c->prs[c->pin], 0, cells_local(c) * sizeof(float), c->stream));
     }
     return;
   }
@@ -322,11 +361,11 @@ void enq_pressure_group(fluid_ctx *c, int g) {
     const int div_m = c->groups > 1 ? glen : -1;
     if (tb && left > 0) {
       // divergence + resetPressure (p^0 == 0 is a constant, not a buffer) + the first sweeps
-      const int k = next_pass(left, c->tb_kj, c->tb_cj, false);
-      ProfScope p(c, K_JACOBI_DIV_TB, 12.0 * cells + 12.0 * k * cells);
+      const int k = next_pass(c, left, false);
+      ProfScope p(c, K_JACOBI_DIV_TB, 12.0 * cells + 12.0 * k * cells, 16.0 * cells);  // velocity in, divergence and p out
       const Range r = widened(c, div_m >= 0 ? div_m : 1 + left - k);
-      launch_jacobi_div_tb(c->stream, c->g, r.r0, r.r1, k, c->tb_cj, tb_chunk(c, k, c->tb_cj, r.r1 - r.r0),
-                           c->vel[c->vin], c->div, c->prs[c->pin ^ 1], c->dump);
+      LAUNCH(c, launch_jacobi_div_tb(c->stream, c->g, r.r0, r.r1, k, c->tb_cj, tb_chunk(c, k, c->tb_cj, r.r1 - r.r0),
+                                  c->vel[c->vin], c->div, c->prs[c->pin ^ 1], c->dump));
       c->pin ^= 1;
       left -= k;
     } else {
@@ -337,16 +376,16 @@ void enq_pressure_group(fluid_ctx *c, int g) {
       }
       // resetPressure()  kernel.cu:530-540: only the pressure clear is live (the
       // other two targets are overwritten before they are read).
-      (void)hipMemsetAsync(c->prs[c->pin], 0, cells_local(c) * sizeof(float), c->stream);
+      HIPNOTE(c, hipMemsetAsync(c->prs[c->pin], 0, cells_local(c) * sizeof(float), c->stream));
     }
   }
   if (tb) {
     while (left > 0) {
-      const int k = next_pass(left, c->tb_kj, c->tb_cj, false);
-      ProfScope p(c, K_JACOBI_TB, 12.0 * k * cells);
+      const int k = next_pass(c, left, false);
+      ProfScope p(c, K_JACOBI_TB, 12.0 * k * cells, 12.0 * cells);
       const Range r = widened(c, 1 + left - k);
-      launch_jacobi_tb(c->stream, c->g, r.r0, r.r1, k, c->tb_cj, tb_chunk(c, k, c->tb_cj, r.r1 - r.r0),
-                       c->prs[c->pin], c->div, c->prs[c->pin ^ 1], c->dump);
+      LAUNCH(c, launch_jacobi_tb(c->stream, c->g, r.r0, r.r1, k, c->tb_cj, tb_chunk(c, k, c->tb_cj, r.r1 - r.r0),
+                              c->prs[c->pin], c->div, c->prs[c->pin ^ 1], c->dump));
       c->pin ^= 1;
       left -= k;
     }
@@ -365,7 +404,7 @@ void enq_gradient(fluid_ctx *c, bool with_density) {
   const double cells = (double)cells_owned(c);
   if (with_density) {
     // + simulateDensityAdvection() kernel.cu:664-685 on the same rows (see enq_step)
-    ProfScope p(c, K_PROJECT_ADVECT_DENS, 60.0 * cells);
+    ProfScope p(c, K_PROJECT_ADVECT_DENS, 60.0 * cells, 52.0 * cells);  // the projected velocity stays in registers
     const Range r = widened(c, 0);
     const Range valid = c->slab ? widened(c, c->halo_dens) : Range{0, c->g.L};
     launch_project_advect_dens(c->stream, c->g, r.r0, r.r1, valid.r0, valid.r1, c->prm.dt,
@@ -393,7 +432,7 @@ void enq_gradient_density_rows(fluid_ctx *c, bool edges) {
   if (edges) {  // both edges in one launch (two launches of ~11 us each are mostly ramp-up and drain)
     const int rows = (lo_end - own.r0) + (own.r1 - hi_beg);
     if (rows > 0) {
-      ProfScope p(c, K_PROJECT_ADVECT_DENS, 60.0 * (double)c->g.n * rows);
+      ProfScope p(c, K_PROJECT_ADVECT_DENS, 60.0 * (double)c->g.n * rows, 52.0 * (double)c->g.n * rows);
       launch_project_advect_dens(c->stream, c->g, own.r0, lo_end, valid.r0, valid.r1, c->prm.dt, c->vel[vi],
                                  c->prs[c->pin], c->vel[vi ^ 1], c->dens[di], c->dens[di ^ 1], c->halo_flag,
                                  false, hi_beg, own.r1);  // regular stores: the edge rows are packed next
@@ -408,7 +447,7 @@ void enq_gradient_density_rows(fluid_ctx *c, bool edges) {
     for (int i = 0; i < k; ++i) {
       const Range r{lo_end + (int)((long)rows * i / k), lo_end + (int)((long)rows * (i + 1) / k)};
       if (r.r1 <= r.r0) continue;
-      ProfScope p(c, K_PROJECT_ADVECT_DENS, 60.0 * (double)c->g.n * (r.r1 - r.r0));
+      ProfScope p(c, K_PROJECT_ADVECT_DENS, 60.0 * (double)c->g.n * (r.r1 - r.r0), 52.0 * (double)c->g.n * (r.r1 - r.r0));
       launch_project_advect_dens(c->stream, c->g, r.r0, r.r1, valid.r0, valid.r1, c->prm.dt, c->vel[vi],
                                  c->prs[c->pin], c->vel[vi ^ 1], c->dens[di], c->dens[di ^ 1], c->halo_flag,
                                  c->nt_stores);
@@ -465,6 +504,12 @@ void enq_step(fluid_ctx *c, int parts) {
 }
 
 int check_launch(fluid_ctx *c) {
+  if (c->enq_rc) {  // a launch_* refused or a memset failed while enqueueing (message already in c->err)
+    const int rc = c->enq_rc;
+    c->enq_rc = 0;
+    (void)hipGetLastError();
+    return rc;
+  }
   hipError_t e = hipGetLastError();  // cudaPeekAtLastError after every launch, e.g. kernel.cu:552
   if (e != hipSuccess) return fail(c, FLUID_E_DEVICE, "kernel launch: %s", hipGetErrorString(e));
   return FLUID_OK;
@@ -476,7 +521,7 @@ int run_steps(fluid_ctx *c, int nsteps, int parts = FLUID_PART_VELOCITY | FLUID_
   // launches it replaces (measured: 2048-row slab of 16384^2 driven in parts).
   const int small_parts = FLUID_PART_DENSITY | FLUID_PART_VELOCITY_TAIL | FLUID_PART_TAIL_DENSITY_EDGES |
                           FLUID_PART_TAIL_DENSITY_INTERIOR | FLUID_PART_ADVECT_INTERIOR;
-  const bool direct = (c->prm.flags & FLUID_FLAG_NO_GRAPH) || c->prof || (env_int("FLUID_DIRECT_PARTS", 1) && (parts & ~small_parts) == 0);
+  const bool direct = (c->prm.flags & FLUID_FLAG_NO_GRAPH) || c->prof || (c->direct_parts && (parts & ~small_parts) == 0);
   // Whole steps of a whole-domain context are captured several to a graph, in power-of-two batches
   // (21 steps = 16 + 4 + 1): a graph launch costs 4-5 us of its own on this runtime, 12 % of the
   // reference's default step (512^2, J = 10: 40.5 -> 35.6 us per step) and what separated graph
@@ -508,6 +553,10 @@ int run_steps(fluid_ctx *c, int nsteps, int parts = FLUID_PART_VELOCITY | FLUID_
       ge.next_state = state_of(c);
       set_state(c, key & 7);
       c->advect_early = early0;
+      if (c->enq_rc) {  // something refused to enqueue: no graph, and the caller hears about it
+        if (e == hipSuccess && ge.graph) (void)hipGraphDestroy(ge.graph);
+        return check_launch(c);
+      }
       if (e != hipSuccess) return fail(c, FLUID_E_DEVICE, "hipStreamEndCapture: %s", hipGetErrorString(e));
       HIPCHK(c, hipGraphInstantiate(&ge.exec, ge.graph, nullptr, nullptr, 0));
       it = c->graphs.emplace(key, ge).first;
@@ -655,6 +704,8 @@ int fluid_init(fluid_ctx **out, const fluid_params *p) {
   c->nt_stores = env_int("FLUID_NT", (long long)prm.n * si.store_rows >= (1ll << 24) ? 1 : 0) != 0;
   c->graph_steps = env_int("FLUID_GRAPH_STEPS", 16);
   if (c->graph_steps < 1) c->graph_steps = 1;
+  c->direct_parts = env_int("FLUID_DIRECT_PARTS", 1) != 0;
+  c->force_k = env_int("FLUID_TEST_FORCE_K", 0);
   c->interior_split = env_int("FLUID_INTERIOR_SPLIT", 4);
   c->interior_split = c->interior_split < 1 ? 1 : c->interior_split > 8 ? 8 : c->interior_split;
   c->interior_piece_min = env_int("FLUID_INTERIOR_PIECE_MIN", 1 << 21);
@@ -664,6 +715,7 @@ int fluid_init(fluid_ctx **out, const fluid_params *p) {
   c->tb_cd = env_int("FLUID_TB_CD", c->tb_cd);
   c->tb_waves = env_int("FLUID_TB_WAVES", c->tb_waves);
   c->tb_minchunk = env_int("FLUID_TB_MINCHUNK", c->tb_minchunk);
+  fill_pass_tables(c);
   c->alpha = 1.0f / (prm.viscosity * prm.dt);  // kernel.cu:182, fp32 at run time
   c->beta = 1.0f / (4.0f + c->alpha);          // kernel.cu:183
   int rc = [&]() -> int {
@@ -882,6 +934,7 @@ int fluid_prepare_steps(fluid_ctx *c, int nsteps) {
 int fluid_time_steps(fluid_ctx *c, int nsteps, float *ms_out) {
   if (!c || nsteps < 0 || !ms_out) return FLUID_E_INVALID;
   if (c->slab && nsteps > 1) return FLUID_E_UNSUPPORTED;
+  if (c->groups > 1 && nsteps > 0) return FLUID_E_UNSUPPORTED;  // as fluid_step: the exchanges between groups are the caller's
   HIPCHK(c, hipSetDevice(c->prm.device));
   {
     int prc = run_steps(c, nsteps, FLUID_PART_VELOCITY | FLUID_PART_DENSITY, false);  // graphs built outside the timed region
@@ -908,6 +961,7 @@ int fluid_profile_steps(fluid_ctx *c, int nsteps, fluid_kernel_stat *stats, int 
                         int *count) {
   if (!c || nsteps < 0 || !stats || !count || max_stats <= 0) return FLUID_E_INVALID;
   if (c->slab && nsteps > 1) return FLUID_E_UNSUPPORTED;
+  if (c->groups > 1 && nsteps > 0) return FLUID_E_UNSUPPORTED;
   HIPCHK(c, hipSetDevice(c->prm.device));
   c->prof = true;
   c->ev_used = 0;
@@ -924,9 +978,13 @@ int fluid_profile_steps(fluid_ctx *c, int nsteps, fluid_kernel_stat *stats, int 
     acc[r.kid].launches += 1;
     acc[r.kid].total_ms += ms;
     acc[r.kid].alg_bytes += r.bytes;
+    acc[r.kid].moved_bytes += r.moved;
   }
   for (int i = 0; i < K_COUNT; ++i)
-    if (acc[i].launches) acc[i].alg_bytes /= acc[i].launches;  // mean per launch
+    if (acc[i].launches) {  // mean per launch
+      acc[i].alg_bytes /= acc[i].launches;
+      acc[i].moved_bytes /= acc[i].launches;
+    }
   int k = 0;
   for (int i = 0; i < K_COUNT && k < max_stats; ++i) {
     if (!acc[i].launches) continue;

@@ -428,12 +428,15 @@ bool diffuse_tile_launch(hipStream_t s, Geom g, int r0, int r1, float alpha, flo
                          float2 *vout) {
   using G = TileGeom<K>;
   constexpr size_t bytes = 4 * (size_t)G::PLANE * sizeof(float);
-  static bool raised = false;  // more than 64 KB of LDS per workgroup is an opt-in, once per kernel
-  if (bytes > 64 * 1024 && !raised) {
+  // more than 64 KB of LDS per workgroup is an opt-in, once per kernel AND device (a context on
+  // another device, fluid_params.device, has its own copy of the code object)
+  static bool raised[64] = {false};
+  int dev = 0;
+  if (bytes > 64 * 1024 && (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || !raised[dev])) {
     if (hipFuncSetAttribute((const void *)k_diffuse_tile<K>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)bytes) != hipSuccess)
       return false;
-    raised = true;
+    if (dev >= 0 && dev < 64) raised[dev] = true;
   }
   k_diffuse_tile<K><<<tile_grid(g, r0, r1), G::THREADS, bytes, s>>>(g, r0, r1, alpha, beta, vin, vout);
   return true;

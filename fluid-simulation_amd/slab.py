@@ -119,11 +119,10 @@ class SlabSim:
         self.torch = torch
         torch.cuda.set_device(device_index)
         self.stream = torch.cuda.Stream(device=device_index)       # kernels, unpack
-        # pack, transfers.  Normal priority: a high-priority stream (FLUID_SLAB_HIGH_PRIORITY=1) lets a
-        # long side-stream kernel in earlier, but with four processes sharing one GPU
-        # it hung tests/test_slab.py::test_slabsim_multiprocess_on_one_gpu[4-overlap] one run in a few
-        self.high_priority = os.environ.get("FLUID_SLAB_HIGH_PRIORITY", "0") == "1"
-        self.comm_stream = torch.cuda.Stream(device=device_index, priority=-1 if self.high_priority else 0)
+        # pack, transfers.  Normal priority, always: a high-priority second stream was tried in round 1
+        # and removed (no gain for these short messages, and its wait on a
+        # normal-priority queue could deadlock when four processes share one GPU's hardware queues).
+        self.comm_stream = torch.cuda.Stream(device=device_index)
         self.sim = pkg.FluidSim(n, device=device_index, slab_rank=rank, slab_count=world, **params)
         self.sim.set_stream(self.stream.cuda_stream)
         self.n, self.row0, self.rows = self.sim.n, self.sim.row0, self.sim.rows

@@ -203,7 +203,11 @@ typedef struct fluid_kernel_stat {
   char name[48];        /* kernel name as it appears in a rocprofv3 trace       */
   int launches;         /* launches in the profiled steps                       */
   float total_ms;       /* sum of launch durations (HIP events, own stream)     */
-  double alg_bytes;     /* algorithmic bytes per launch  */
+  double alg_bytes;     /* algorithmic bytes per launch: the
+                           bytes of the reference launches this launch stands for   */
+  double moved_bytes;   /* bytes the launch itself must move (each input read once,
+                           each output written once): < alg_bytes where launches are
+                           fused (K sweeps per launch; projection + density advection) */
 } fluid_kernel_stat;
 
 /* Run nsteps steps with direct launches, each launch bracketed by HIP events

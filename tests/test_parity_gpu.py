@@ -225,12 +225,96 @@ def test_large_grid_fused_equals_unfused(pkg, hip):
         assert_bit_equal(a, b, f"8192^2 {f}")
 
 
+def test_config0_100_steps_seeded(pkg, hip, oracle):
+    """BASELINE.json configs[0] verbatim: the reference's default grid (512^2, D = J = 10), seeded
+    splats before step 0 and every 10th step, 100 steps, HIP against the serial host-C
+    transcription.  Only expf in the splat may differ; the bar is north_star's 1e-5 per field for
+    velocity, density and pressure (the divergence buffer, a difference of nearly equal
+    neighbours, is held to the drift bound)."""
+    n, steps = 512, 100
+    gpu, ref = pair(pkg, hip, oracle, n)
+    pkg.run_seeded(gpu, steps)
+    pkg.run_seeded(ref, steps)
+    a, b = read_all(gpu, pkg), read_all(ref, pkg)
+    e = {f: rel_err(a[f], b[f]) for f in FIELDS}
+    print("config0, 100 steps: " + ", ".join(f"{k}={v:.2e}" for k, v in e.items()))
+    for f in ("velocity", "density", "pressure"):
+        assert e[f] <= 1e-5, (f, e[f])
+    assert e["divergence"] <= 1e-4, e["divergence"]
+
+
+def test_config1_1024_J40_graph_two_steps_bit_exact(pkg, hip, oracle):
+    """BASELINE.json configs[1] at full size (1024^2, J = 40, hipGraph replay; the LDS-tile path at
+    its largest grid): two steps from an injected post-splat state, bit for bit against the
+    oracle (120 ms of CPU)."""
+    n, J = 1024, 40
+    gpu, ref = pair(pkg, hip, oracle, n, pressure_iters=J)
+    ss = pkg.SplatStream()
+    for _ in range(3):
+        ref.add_source(*ss.splat())
+    vel, dens = ref.read(pkg.FIELD_VELOCITY), ref.read(pkg.FIELD_DENSITY)
+    vel *= np.float32(25.0)   # backtraces of several cells
+    ref.write(pkg.FIELD_VELOCITY, vel)
+    gpu.write(pkg.FIELD_VELOCITY, vel)
+    gpu.write(pkg.FIELD_DENSITY, dens)
+    gpu.prepare_steps(2)
+    gpu.step(2)
+    ref.step(2)
+    a, b = read_all(gpu, pkg), read_all(ref, pkg)
+    for f in FIELDS:
+        assert_bit_equal(a[f], b[f], f"1024^2 J=40 {f}")
+
+
+def test_full_size_16384_fused_equals_unfused(pkg, hip):
+    """BASELINE.json configs[3] at full size on one GPU: one step of the fused path (temporal
+    blocking, fused last kernel, non-temporal stores, the 16384-wave plan) against the straight
+    one-launch-per-reference-launch path, bit for bit, one field at a time (4.3 GB each on the
+    host).  The straight kernels are the ones compared with the oracle at small sizes."""
+    n, J = 16384, 40
+    sims = [pkg.FluidSim(n, lib=hip, pressure_iters=J, flags=flags) for flags in (0, pkg.FLAG_UNFUSED)]
+    for s in sims:
+        ss = pkg.SplatStream()
+        for _ in range(4):
+            sx, sy, fx, fy, rgba = ss.splat()
+            s.add_source(sx, sy, 60 * fx, 60 * fy, rgba)
+        s.step(1)
+    for f, fid in (("velocity", pkg.FIELD_VELOCITY), ("pressure", pkg.FIELD_PRESSURE),
+                   ("divergence", pkg.FIELD_DIVERGENCE), ("density", pkg.FIELD_DENSITY)):
+        a = sims[0].read(fid)
+        b = sims[1].read(fid)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"16384^2 {f}: fused != unfused"
+        assert float(np.abs(a).max()) > 0
+        del a, b
+    for s in sims:
+        s.close()
+
+
+@pytest.mark.parametrize("n,flags", [(256, 0), (256, 2), (2048, 0), (2048, 2)],
+                         ids=["tiles-graph", "tiles-direct", "pipeline-graph", "pipeline-direct"])
+def test_a_refused_launch_is_reported(pkg, hip, n, flags, monkeypatch):
+    """launch_*_tb / launch_*_tile return false for a sweep count the build does not hold.  The
+    planner (next_pass) never asks for one; FLUID_TEST_FORCE_K bypasses it, and the step must then
+    fail with FLUID_E_UNSUPPORTED — never FLUID_OK with a stale buffer as the current field."""
+    monkeypatch.setenv("FLUID_TEST_FORCE_K", "7")   # no 7-sweep kernel exists
+    sim = pkg.FluidSim(n, lib=hip, flags=flags)
+    with pytest.raises(pkg.FluidError) as ei:
+        sim.step(1)
+        sim.sync()
+    assert ei.value.code == -7 and "refused" in str(ei.value)
+    sim.close()
+    monkeypatch.delenv("FLUID_TEST_FORCE_K")
+    ok = pkg.FluidSim(n, lib=hip, flags=flags)      # the same shape is fine through the planner
+    ok.step(1)
+    ok.sync()
+    ok.close()
+
+
 def test_drift_1000_steps(pkg, hip, oracle):
-    """north_star: bounded drift after 1000 steps (reference defaults D=10/J=10, seeded splats).
-    N=256 by default so the serial oracle finishes in ~20 s; FLUID_LONG=1 runs the reference's
-    N=512, ~80 s of CPU."""
+    """north_star: bounded drift after 1000 steps (reference defaults D=10/J=10, seeded splats)
+    at the reference's N=512 (~80 s of the serial oracle).  FLUID_SHORT=1 runs
+    N=256 instead."""
     import os
-    n, steps = (512 if os.environ.get("FLUID_LONG") else 256), 1000
+    n, steps = (256 if os.environ.get("FLUID_SHORT") else 512), 1000
     gpu, ref = pair(pkg, hip, oracle, n)
     ss_a, ss_b = pkg.SplatStream(), pkg.SplatStream()
     errs = []

@@ -395,3 +395,50 @@ def test_baseline_multi_gpu_configs_at_full_size(pkg, hip, n, J, count):
     assert dw["max_abs_u"] > 0 and sum(dw["dye"]) > 0
     group.close()
     whole.close()
+
+
+@pytest.mark.gpu
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher: the parent (which never touches the GPU) starts
+    the two ranks itself, relays rank 0's JSON line and exits 0.  Rehearsal transport: gloo, both
+    ranks on GPU 0 (RCCL refuses two ranks per device); the measured configuration differs only in
+    the backend and the device index."""
+    import json
+    env = dict(os.environ, FLUID_BENCH_BACKEND="gloo", FLUID_BENCH_ONE_GPU="1", GLOO_SOCKET_IFNAME="lo",
+               FLUID_BENCH_TIMEOUT="300")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "1024_J40",
+                          "--steps", "3", "--warmup", "1"], env=env, capture_output=True, text=True, timeout=400)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["overlap_matches_plain_exchange"] is True
+    assert rec["value"] > 0 and rec["unit"] == "GCUPS"
+
+
+def test_bench_launcher_reports_a_failed_rank(tmp_path):
+    """The launcher half alone, on CPU: a rank that dies makes the parent end the others and exit
+    non-zero; a job that outlives FLUID_BENCH_TIMEOUT is ended with 124."""
+    sys.path.insert(0, ROOT)
+    import importlib
+    bench = importlib.import_module("bench")
+    script = tmp_path / "rank.py"
+    script.write_text("import os, sys, time\n"
+                      "r = int(os.environ['RANK'])\n"
+                      "assert os.environ['WORLD_SIZE'] == '3' and os.environ['MASTER_ADDR'] == '127.0.0.1'\n"
+                      "mode = sys.argv[1]\n"
+                      "if mode == 'ok': print('{\"rank\": %d}' % r) if r == 0 else None\n"
+                      "elif mode == 'die' and r == 1: sys.exit(3)\n"
+                      "else: time.sleep(60)\n")
+    real = bench.__file__
+    try:
+        bench.__file__ = str(script)          # launch_ranks starts children of "this file"
+        assert bench.launch_ranks(3, ["ok"]) == 0
+        assert bench.launch_ranks(3, ["die"]) == 1
+        os.environ["FLUID_BENCH_TIMEOUT"] = "1"
+        assert bench.launch_ranks(3, ["hang"]) == 124
+    finally:
+        bench.__file__ = real
+        os.environ.pop("FLUID_BENCH_TIMEOUT", None)

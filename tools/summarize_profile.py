@@ -52,6 +52,17 @@ if len(sys.argv) > 3:  # also write the table bench.py reads for roofline.traffi
     table = dict(out["traffic_by_kernel_family"])
     table["_workload"] = sys.argv[4] if len(sys.argv) > 4 else "16384_J40"  # bench.py applies it to this workload only
     table["_source"] = dst + ".json"
+    import datetime
+    import subprocess
+    try:   # the commit the profiled tree was taken from (this script runs in the repo, after the GPU call)
+        table["_commit"] = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True,
+                                          check=True).stdout.strip()
+        if subprocess.run(["git", "status", "--porcelain", "--untracked-files=no"], capture_output=True,
+                          text=True).stdout.strip():
+            table["_commit"] += "+uncommitted"
+    except Exception:
+        table["_commit"] = None
+    table["_date"] = datetime.date.today().isoformat()
     json.dump(table, open(sys.argv[3], "w"), indent=1, sort_keys=True)
 json.dump(out, open(dst + ".json", "w"), indent=1, sort_keys=True)
 with open(dst + ".txt", "w") as fh:
