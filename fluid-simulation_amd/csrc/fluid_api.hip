@@ -13,8 +13,37 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <new>
 #include <vector>
+
+// ---- scratch of the entry point that allocates nothing (fluid_step_noalloc) ----------------
+// The temporally blocked kernels write the rows a wave computes but must not store to a dump row
+// (fluid_kernels_tb.hip, "Every load and store below is UNCONDITIONAL"): n * 8 bytes are used, the
+// contexts allocate n * 16 + 256.  fluid_step_noalloc hands the kernels this file-scope array
+// instead, sized for its stated maximum grid edge.  One copy per GPU the library runs on, held
+// until the process ends.  Host code never uses the array's NAME as an address (on the host it is
+// a stand-in, not device memory): the device address is taken once per device with
+// hipGetSymbolAddress (scratch_setup, called by fluid_init with that device current) and kept in
+// g_scratch_ptr[device]; kernels get that pointer as their `dump` argument.
+#define FLUID_NOALLOC_SCRATCH_BYTES ((size_t)FLUID_NOALLOC_MAX_N * 16 + 256)
+static __device__ __align__(256) unsigned char scratch[FLUID_NOALLOC_SCRATCH_BYTES];
+static constexpr int kMaxDevices = 64;
+static void *g_scratch_ptr[kMaxDevices] = {nullptr};
+static std::mutex g_scratch_mutex;
+
+// With `device` current.  hipSuccess and a non-null pointer, or the error of the lookup.
+static hipError_t scratch_setup(int device) {
+  if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (g_scratch_ptr[device]) return hipSuccess;
+  void *ptr = nullptr;
+  const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+  if (e != hipSuccess) return e;
+  if (!ptr) return hipErrorInvalidSymbol;
+  g_scratch_ptr[device] = ptr;
+  return hipSuccess;
+}
 
 namespace {
 
@@ -720,6 +749,7 @@ int fluid_init(fluid_ctx **out, const fluid_params *p) {
   c->beta = 1.0f / (4.0f + c->alpha);          // kernel.cu:183
   int rc = [&]() -> int {
     HIPCHK(c, hipSetDevice(prm.device));
+    HIPCHK(c, scratch_setup(prm.device));  // this device's copy of the static scratch (fluid_step_noalloc)
     HIPCHK(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     const size_t nc = cells_local(c);
@@ -810,6 +840,32 @@ int fluid_step(fluid_ctx *c, int nsteps) {
   if (c->groups > 1 && nsteps > 0) return FLUID_E_UNSUPPORTED;  // pressure halos between groups: fluid_step_part
   HIPCHK(c, hipSetDevice(c->prm.device));
   return run_steps(c, nsteps);
+}
+
+// fluid_step for callers that cannot allocate (include/fluid.h): direct launches (no graph is
+// captured or instantiated), the pass plan from the tables fluid_init filled, and the dump row of
+// the temporally blocked kernels in this GPU's static scratch instead of the context's hipMalloc'ed
+// row.  Calls no hipMalloc / hipFree / allocating routine.  The dump row is write-only garbage
+// (never read), so nothing has to be cleared between calls; it is shared by every call on the GPU.
+int fluid_step_noalloc(fluid_ctx *c, int nsteps) {
+  if (!c || nsteps < 0) return FLUID_E_INVALID;
+  if (c->slab) return FLUID_E_UNSUPPORTED;  // halos must be refreshed before every step (fluid_step_part)
+  if (c->g.n > FLUID_NOALLOC_MAX_N)
+    return fail(c, FLUID_E_SIZE, "fluid_step_noalloc: n = %d is beyond the static scratch (n <= %d, %zu bytes)",
+                c->g.n, FLUID_NOALLOC_MAX_N, FLUID_NOALLOC_SCRATCH_BYTES);
+  if ((size_t)c->g.n * 16 + 256 > FLUID_NOALLOC_SCRATCH_BYTES) return FLUID_E_SIZE;
+  void *const ptr = g_scratch_ptr[c->prm.device];  // set by fluid_init on this device
+  if (!ptr) return fail(c, FLUID_E_DEVICE, "fluid_step_noalloc: no scratch address for device %d", c->prm.device);
+  HIPCHK(c, hipSetDevice(c->prm.device));
+  void *const own_dump = c->dump;
+  c->dump = ptr;
+  int rc = FLUID_OK;
+  for (int s = 0; s < nsteps && rc == FLUID_OK; ++s) {
+    enq_step(c, FLUID_PART_VELOCITY | FLUID_PART_DENSITY);
+    rc = check_launch(c);
+  }
+  c->dump = own_dump;
+  return rc;
 }
 
 // Single stages are whole-domain only: in a slab the row range a stage must cover depends on

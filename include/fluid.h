@@ -130,6 +130,19 @@ FLUID_API int fluid_step(fluid_ctx *ctx, int nsteps);
  * callers that want the first fluid_step of a given length to cost what the later ones do. */
 FLUID_API int fluid_prepare_steps(fluid_ctx *ctx, int nsteps);
 
+/* fluid_step for callers that cannot allocate: code under HIP graph capture (with the context on
+ * the capturing stream, fluid_set_stream), tight serving loops, harnesses that forbid hipMalloc.
+ * No counterpart in the reference.  Same kernels, same results as fluid_step, bit for bit; it
+ * launches them directly (fluid_step captures and instantiates hipGraphs on first use, which
+ * allocates) and gives the temporally blocked kernels their dump row (the sink for rows a wave
+ * computes but must not store) in a file-scope device array of FLUID_NOALLOC_MAX_N * 16 + 256
+ * bytes (256.25 KiB, one copy per GPU, held until the process ends) instead of the context's own.
+ * Calls no hipMalloc / hipFree / allocating routine.  n > FLUID_NOALLOC_MAX_N: FLUID_E_SIZE; slab
+ * contexts: FLUID_E_UNSUPPORTED.  Every call on a GPU shares that GPU's array: its contents are
+ * never read, so nothing is cleared between calls and calls of different contexts may overlap. */
+#define FLUID_NOALLOC_MAX_N 16384
+FLUID_API int fluid_step_noalloc(fluid_ctx *ctx, int nsteps);
+
 /* The four stage functions simulationStep() is made of, individually
  * (kernel.cu:542-555, :582-602, :604-662, :664-685) and the optional
  * simulateVorticity() (:557-580).  fluid_step == advect_velocity, diffuse,
