@@ -9,6 +9,7 @@ There is no CPU fallback: constructing a :class:`FluidSim` without the built HIP
 library or without a GPU raises.  Nothing in this package imports ``oracle/``.
 """
 from .capi import (FluidLib, FluidSim, FluidError, FluidParams, FluidDiag, KernelStat, SlabInfo, hip_lib_path,
+                   FluidTransport, FluidCommStats, COMM_ID_BYTES,
                    FIELD_VELOCITY, FIELD_DENSITY, FIELD_PRESSURE, FIELD_DIVERGENCE,
                    FIELD_VORTICITY, FLAG_VORTICITY, FLAG_NO_GRAPH, FLAG_UNFUSED, ABI_SYMBOLS, PART_VELOCITY, PART_DENSITY,
                    PART_VELOCITY_HEAD, PART_PRESSURE_GROUP, PART_VELOCITY_TAIL,
@@ -19,6 +20,7 @@ from .splats import SplatStream, COLOR_PRESETS, alg_bytes_per_cell, run_seeded, 
 
 __all__ = [
     "FluidLib", "FluidSim", "FluidError", "FluidParams", "FluidDiag", "KernelStat", "hip_lib_path",
+    "FluidTransport", "FluidCommStats", "COMM_ID_BYTES",
     "FIELD_VELOCITY", "FIELD_DENSITY", "FIELD_PRESSURE", "FIELD_DIVERGENCE", "FIELD_VORTICITY",
     "FLAG_VORTICITY", "FLAG_NO_GRAPH", "FLAG_UNFUSED", "ABI_SYMBOLS", "PART_VELOCITY", "PART_DENSITY",
     "PART_VELOCITY_HEAD", "PART_PRESSURE_GROUP", "PART_VELOCITY_TAIL",

@@ -27,7 +27,10 @@ ABI_SYMBOLS = [
     "fluid_stream", "fluid_set_stream",
     "fluid_slab_plan", "fluid_halo_bytes", "fluid_halo_pack", "fluid_halo_unpack",
     "fluid_step_part", "fluid_halo_bytes_part", "fluid_halo_pack_part", "fluid_halo_unpack_part",
+    "fluid_comm_unique_id", "fluid_comm_init_rccl", "fluid_comm_attach_rccl", "fluid_comm_attach",
+    "fluid_comm_detach", "fluid_comm_refresh", "fluid_comm_info", "fluid_comm_selftest_rccl",
 ]
+COMM_ID_BYTES = 128
 PART_VELOCITY, PART_DENSITY = 1, 2
 PART_VELOCITY_HEAD, PART_PRESSURE_GROUP, PART_VELOCITY_TAIL = 4, 8, 16
 PART_TAIL_DENSITY_EDGES, PART_TAIL_DENSITY_INTERIOR = 32, 64
@@ -68,6 +71,29 @@ class FluidDiag(C.Structure):
         d = {k: float(getattr(self, k)) for k in self.MAX_KEYS}
         d["dye"] = [float(x) for x in self.dye]
         return d
+
+
+# fluid_transport: the four callbacks of a caller-provided halo transport
+TRANSPORT_GROUP_START = C.CFUNCTYPE(C.c_int, C.c_void_p)
+TRANSPORT_SEND = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
+TRANSPORT_RECV = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
+TRANSPORT_GROUP_END = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
+
+
+class FluidTransport(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("group_start", TRANSPORT_GROUP_START), ("send", TRANSPORT_SEND),
+                ("recv", TRANSPORT_RECV), ("group_end", TRANSPORT_GROUP_END), ("capturable", C.c_int)]
+
+
+class FluidCommStats(C.Structure):
+    _fields_ = [("attached", C.c_int), ("capturable", C.c_int), ("graph", C.c_int), ("graphs_built", C.c_int),
+                ("exchanges", C.c_longlong), ("bytes_sent", C.c_longlong), ("transport", C.c_char * 16),
+                ("note", C.c_char * 160)]
+
+    def as_dict(self):
+        return {"attached": bool(self.attached), "capturable": bool(self.capturable), "graph": bool(self.graph),
+                "graphs_built": self.graphs_built, "exchanges": self.exchanges, "bytes_sent": self.bytes_sent,
+                "transport": self.transport.decode(), "note": self.note.decode()}
 
 
 class FluidError(RuntimeError):
@@ -144,6 +170,30 @@ class FluidLib:
         sig("fluid_halo_bytes_part", C.c_size_t, P, C.c_int, C.c_int, required=False)
         sig("fluid_halo_pack_part", C.c_int, P, C.c_int, C.c_int, P, P, required=False)
         sig("fluid_halo_unpack_part", C.c_int, P, C.c_int, C.c_int, P, P, required=False)
+
+        sig("fluid_comm_unique_id", C.c_int, P, C.c_size_t, required=False)
+        sig("fluid_comm_init_rccl", C.c_int, P, P, C.c_size_t, required=False)
+        sig("fluid_comm_attach_rccl", C.c_int, P, P, required=False)
+        sig("fluid_comm_attach", C.c_int, P, C.POINTER(FluidTransport), required=False)
+        sig("fluid_comm_detach", C.c_int, P, required=False)
+        sig("fluid_comm_refresh", C.c_int, P, required=False)
+        sig("fluid_comm_info", C.c_int, P, C.POINTER(FluidCommStats), required=False)
+        sig("fluid_comm_selftest_rccl", C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_char_p, C.c_size_t, required=False)
+
+    def comm_unique_id(self) -> bytes:
+        """fluid_comm_unique_id (ncclGetUniqueId): rank 0 makes it, every rank passes it to comm_init_rccl."""
+        buf = C.create_string_buffer(COMM_ID_BYTES)
+        rc = self.dll.fluid_comm_unique_id(buf, COMM_ID_BYTES)
+        if rc:
+            raise FluidError(rc, "fluid_comm_unique_id", self.dll.fluid_strerror(rc).decode())
+        return buf.raw
+
+    def comm_selftest_rccl(self, device=0, nbytes=1 << 20, use_graph=True) -> str:
+        msg = C.create_string_buffer(256)
+        rc = self.dll.fluid_comm_selftest_rccl(device, nbytes, int(use_graph), msg, 256)
+        if rc:
+            raise FluidError(rc, "fluid_comm_selftest_rccl", msg.value.decode())
+        return msg.value.decode()
 
     def slab_plan(self, n, slab_rank, slab_count, *, diffusion_iters=None, pressure_iters=None,
                   halo_rows=0, pressure_groups=0) -> dict:
@@ -354,6 +404,29 @@ class FluidSim:
     def halo_unpack_part(self, direction: int, part: int, dev_ptr: int, stream: int = 0):
         self._chk(self.lib.dll.fluid_halo_unpack_part(self._h, direction, part, C.c_void_p(dev_ptr),
                                                       C.c_void_p(stream)), "fluid_halo_unpack_part")
+
+    # -- halo transport under the C ABI ---------------------------------------------
+    def comm_init_rccl(self, unique_id: bytes):
+        """fluid_comm_init_rccl: collective; afterwards step(n) exchanges the halos itself over RCCL."""
+        self._chk(self.lib.dll.fluid_comm_init_rccl(self._h, unique_id, len(unique_id)), "fluid_comm_init_rccl")
+
+    def comm_attach(self, transport: "FluidTransport"):
+        """fluid_comm_attach: a caller-provided transport (keep `transport` alive while attached)."""
+        self._transport = transport
+        self._chk(self.lib.dll.fluid_comm_attach(self._h, C.byref(transport)), "fluid_comm_attach")
+
+    def comm_detach(self):
+        self._chk(self.lib.dll.fluid_comm_detach(self._h), "fluid_comm_detach")
+        self._transport = None
+
+    def comm_refresh(self):
+        """fluid_comm_refresh: halo rows of the current state in place (collective)."""
+        self._chk(self.lib.dll.fluid_comm_refresh(self._h), "fluid_comm_refresh")
+
+    def comm_info(self) -> dict:
+        st = FluidCommStats()
+        self._chk(self.lib.dll.fluid_comm_info(self._h, C.byref(st)), "fluid_comm_info")
+        return st.as_dict()
 
     def stream(self) -> int:
         return self.lib.dll.fluid_stream(self._h) or 0

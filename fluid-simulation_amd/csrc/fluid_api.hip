@@ -51,6 +51,7 @@ struct GraphEntry {
   hipGraphExec_t exec = nullptr;
   hipGraph_t graph = nullptr;
   int next_state = 0;
+  long long exchanges = 0, bytes = 0;  // halo exchanges / bytes sent per launch (slab graphs with a transport)
 };
 
 struct ProfRec {
@@ -97,6 +98,18 @@ struct fluid_ctx {
   bool direct_parts = true;  // step parts of one or two kernels are launched directly, not as graphs (FLUID_DIRECT_PARTS)
   int interior_split = 4;  // launches FLUID_PART_TAIL_DENSITY_INTERIOR is cut into (at most)
   int interior_piece_min = 1 << 21;  // ... each of at least this many cells
+  // halo transport under the C ABI (fluid_comm_attach*): with one attached, fluid_step on a slab
+  // context exchanges the halos itself, on comm_stream, overlapped with the interior launches
+  Transport tr;
+  bool has_comm = false;
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t ev_ready = nullptr, ev_halo = nullptr;  // compute -> comm ("rows are final"), comm -> compute ("halos landed")
+  int halo_state = 0;        // HALO_NONE / HALO_POSTED / HALO_JOINED, see comm_step
+  bool comm_graph = true;    // capture whole slab steps (both streams + the transport's calls) as hipGraphs
+  bool early_advect = true;  // FLUID_PART_ADVECT_INTERIOR before the halos are waited for (FLUID_SLAB_EARLY_ADVECT)
+  long long comm_exchanges = 0, comm_bytes = 0;
+  char comm_note[160] = {0};  // why graph capture was given up, if it was
+  std::map<int, GraphEntry> comm_graphs;
   bool prof = false;
   int enq_rc = 0;          // first failure while enqueueing (a launch_* that refused, a failed memset); see check_launch
   std::vector<hipEvent_t> ev_pool;
@@ -148,11 +161,13 @@ inline int state_of(const fluid_ctx *c) { return c->vin | (c->din << 1) | (c->pi
 inline void set_state(fluid_ctx *c, int s) { c->vin = s & 1; c->din = (s >> 1) & 1; c->pin = (s >> 2) & 1; }
 
 void drop_graphs(fluid_ctx *c) {
-  for (auto &kv : c->graphs) {
-    if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
-    if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
+  for (auto *m : {&c->graphs, &c->comm_graphs}) {
+    for (auto &kv : *m) {
+      if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+      if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
+    }
+    m->clear();
   }
-  c->graphs.clear();
 }
 
 // ---- per-launch profiling (fluid_profile_steps) -----------------------------
@@ -801,7 +816,12 @@ void fluid_destroy(fluid_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->prm.device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
   drop_graphs(c);
+  if (c->has_comm && c->tr.destroy) c->tr.destroy(c->tr.user);
+  if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
+  if (c->ev_halo) (void)hipEventDestroy(c->ev_halo);
+  if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   if (c->arena) (void)hipFree(c->arena);
   if (c->vort) (void)hipFree(c->vort);
@@ -815,6 +835,7 @@ void fluid_destroy(fluid_ctx *c) {
 int fluid_reset(fluid_ctx *c) {
   if (!c) return FLUID_E_INVALID;
   c->advect_early = false;  // rows advected ahead of the step are stale now (recomputed by the full launch)
+  c->halo_state = 0;        // and so are halos already exchanged or on their way (fluid_comm_*)
   HIPCHK(c, hipSetDevice(c->prm.device));
   const size_t nc = cells_local(c);
   HIPCHK(c, hipMemsetAsync(c->vel[c->vin], 0, nc * sizeof(float2), c->stream));
@@ -826,6 +847,7 @@ int fluid_reset(fluid_ctx *c) {
 int fluid_add_source(fluid_ctx *c, float sx, float sy, float fx, float fy, const float rgba[4]) {
   if (!c || !rgba) return FLUID_E_INVALID;
   c->advect_early = false;  // rows advected ahead of the step are stale now (recomputed by the full launch)
+  c->halo_state = 0;
   HIPCHK(c, hipSetDevice(c->prm.device));
   ProfScope p(c, K_ADD_FORCE, 48.0 * (double)cells_owned(c));
   launch_add_force(c->stream, c->g, c->own_r0, c->own_r0 + c->rows, c->prm.dt, c->prm.splat_radius,
@@ -834,8 +856,14 @@ int fluid_add_source(fluid_ctx *c, float sx, float sy, float fx, float fy, const
   return check_launch(c);
 }
 
+static int run_comm_steps(fluid_ctx *c, int nsteps);
+
 int fluid_step(fluid_ctx *c, int nsteps) {
   if (!c || nsteps < 0) return FLUID_E_INVALID;
+  if (c->slab && c->has_comm) {  // the library exchanges the halos itself (fluid_comm_attach*)
+    HIPCHK(c, hipSetDevice(c->prm.device));
+    return run_comm_steps(c, nsteps);
+  }
   if (c->slab && nsteps > 1) return FLUID_E_UNSUPPORTED;  // halos must be refreshed before every step
   if (c->groups > 1 && nsteps > 0) return FLUID_E_UNSUPPORTED;  // pressure halos between groups: fluid_step_part
   HIPCHK(c, hipSetDevice(c->prm.device));
@@ -907,6 +935,7 @@ int fluid_read(fluid_ctx *c, int field, void *dst, size_t dst_bytes) {
 int fluid_write(fluid_ctx *c, int field, const void *srcv, size_t src_bytes) {
   if (!c || !srcv) return FLUID_E_INVALID;
   c->advect_early = false;  // rows advected ahead of the step are stale now (recomputed by the full launch)
+  c->halo_state = 0;
   if (field == FLUID_VORTICITY) {
     int r = ensure_vort(c);
     if (r) return r;
@@ -927,6 +956,7 @@ int fluid_sync(fluid_ctx *c) {
   if (!c) return FLUID_E_INVALID;
   HIPCHK(c, hipSetDevice(c->prm.device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->comm_stream) HIPCHK(c, hipStreamSynchronize(c->comm_stream));  // halos posted for the next step
   return check_halo_flag(c);
 }
 
@@ -989,6 +1019,7 @@ int fluid_prepare_steps(fluid_ctx *c, int nsteps) {
 
 int fluid_time_steps(fluid_ctx *c, int nsteps, float *ms_out) {
   if (!c || nsteps < 0 || !ms_out) return FLUID_E_INVALID;
+  if (c->slab && c->has_comm) return FLUID_E_UNSUPPORTED;  // time fluid_step from outside (two streams)
   if (c->slab && nsteps > 1) return FLUID_E_UNSUPPORTED;
   if (c->groups > 1 && nsteps > 0) return FLUID_E_UNSUPPORTED;  // as fluid_step: the exchanges between groups are the caller's
   HIPCHK(c, hipSetDevice(c->prm.device));
@@ -1081,6 +1112,7 @@ int fluid_step_part(fluid_ctx *c, int part) {
       return FLUID_E_INVALID;
   }
   HIPCHK(c, hipSetDevice(c->prm.device));
+  c->halo_state = 0;  // driven in parts: the halos are the caller's business from here on
   const int rc = run_steps(c, 1, part);
   if (rc) return rc;
   if (part == FLUID_PART_VELOCITY_HEAD) c->pgroup = 1;
@@ -1168,6 +1200,284 @@ int fluid_halo_unpack(fluid_ctx *c, int dir, const void *src) {
   launch_copy_block(c->stream, c->vel[c->vin] + rv * n, src, vb);
   launch_copy_block(c->stream, c->dens[c->din] + rd * n, (const char *)src + vb, db);
   return check_launch(c);
+}
+
+
+// ---- halo exchange under the C ABI ------------------------------------------------------------
+// No counterpart in the reference (single GPU).  With a transport attached, fluid_step on a slab
+// context is the whole multi-GPU step: it posts the halo exchange itself (one group per step:
+// velocity and density blocks to and from both neighbours), straight out of and into the field
+// rows (a halo block is whole rows, hence contiguous: no staging copies), on a second stream, and
+// overlaps it with the interior launches exactly as fluid_step_part lets a caller do by hand:
+//
+//   [interior rows of the advection]  wait for the halos  advection of the rest, diffusion,
+//   divergence + pressure sweeps  gradient subtraction + density advection on the EDGE rows
+//   -> post the exchange for the next step ->  the same on the INTERIOR rows
+//
+// halo_state: HALO_NONE    no exchange of the current state has been posted (fresh context, or
+//                          fluid_add_source / fluid_reset / fluid_write changed the owned rows)
+//             HALO_POSTED  posted on comm_stream, ev_halo recorded behind it
+//             HALO_JOINED  the compute stream has waited for it: the halo rows are in place
+// Every rank must make the same calls in the same order (SPMD), as with any collective.
+enum { HALO_NONE = 0, HALO_POSTED = 1, HALO_JOINED = 2 };
+
+static int post_exchange(fluid_ctx *c, int parts) {
+  Transport &T = c->tr;
+  HIPCHK(c, hipEventRecord(c->ev_ready, c->stream));           // everything enqueued so far ...
+  HIPCHK(c, hipStreamWaitEvent(c->comm_stream, c->ev_ready, 0));  // ... precedes the transfers
+  int rc = T.group_start(T.user);
+  if (rc) return fail(c, FLUID_E_COMM, "%s group start: %s", T.name, T.error ? T.error(T.user) : "");
+  for (int dir = -1; dir <= 1; dir += 2) {
+    if (dir < 0 ? !c->has_lo : !c->has_hi) continue;
+    const int peer = c->prm.slab_rank + dir;
+    for (int part : {FLUID_PART_VELOCITY, FLUID_PART_DENSITY, FLUID_PART_PRESSURE_GROUP}) {
+      HaloField f;
+      if (!(parts & part) || !halo_field(c, part, &f) || f.rows <= 0) continue;
+      const size_t row = (size_t)c->g.n * f.esize, bytes = f.rows * row;
+      const size_t rs = dir < 0 ? c->own_r0 : c->own_r0 + c->rows - f.rows;  // owned rows next to that neighbour
+      const size_t rr = dir < 0 ? c->own_r0 - f.rows : c->own_r0 + c->rows;  // halo rows just outside the owned rows
+      if (!rc) rc = T.send(T.user, f.base + rs * row, bytes, peer, c->comm_stream);
+      if (!rc) rc = T.recv(T.user, f.base + rr * row, bytes, peer, c->comm_stream);
+      c->comm_bytes += (long long)bytes;
+    }
+  }
+  const int rc2 = T.group_end(T.user, c->comm_stream);
+  if (rc || rc2) return fail(c, FLUID_E_COMM, "%s exchange: %s", T.name, T.error ? T.error(T.user) : "");
+  HIPCHK(c, hipEventRecord(c->ev_halo, c->comm_stream));
+  ++c->comm_exchanges;
+  return FLUID_OK;
+}
+
+static int wait_exchange(fluid_ctx *c) {
+  HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_halo, 0));
+  return FLUID_OK;
+}
+
+// One step, enqueue only: the same code runs eagerly and under stream capture.
+static int comm_step(fluid_ctx *c) {
+  const int VD = FLUID_PART_VELOCITY | FLUID_PART_DENSITY;
+  const bool split = !(c->prm.flags & FLUID_FLAG_UNFUSED);  // the fused last kernel in two parts
+  int rc;
+  if (c->halo_state == HALO_NONE) {
+    if ((rc = post_exchange(c, VD))) return rc;
+    c->halo_state = HALO_POSTED;
+  }
+  if (c->halo_state == HALO_POSTED) {
+    // the interior rows of this step's advection read no halo row: more cover for the message
+    if (c->early_advect && !c->advect_early) enq_advect_interior(c);
+    if ((rc = wait_exchange(c))) return rc;
+    c->halo_state = HALO_JOINED;
+  }
+  enq_velocity_head(c);
+  for (int g = 1; g < c->groups; ++g) {  // deep pressure loops on short slabs: exposed exchanges between groups
+    if ((rc = post_exchange(c, FLUID_PART_PRESSURE_GROUP))) return rc;
+    if ((rc = wait_exchange(c))) return rc;
+    enq_pressure_group(c, g);
+  }
+  if (split) {
+    enq_gradient_density_rows(c, true);   // the rows the neighbours wait for; flips to the new buffers
+    if ((rc = post_exchange(c, VD))) return rc;  // they travel while the interior rows are computed
+    c->halo_state = HALO_POSTED;
+    enq_gradient_density_rows(c, false);
+  } else {
+    enq_gradient(c, false);
+    enq_advect_density(c);
+    c->halo_state = HALO_NONE;
+  }
+  c->pgroup = 0;
+  c->tail_edges_done = false;
+  return check_launch(c);
+}
+
+static int run_comm_steps(fluid_ctx *c, int nsteps) {
+  for (int s = 0; s < nsteps;) {
+    const bool graph = c->comm_graph && c->tr.capturable && !(c->prm.flags & FLUID_FLAG_NO_GRAPH) && !c->prof;
+    if (!graph) {
+      const int rc = comm_step(c);
+      if (rc) return rc;
+      ++s;
+      continue;
+    }
+    // A graph starts and ends with the halos in place (an event recorded outside a capture cannot
+    // be waited for inside it): bring the state there eagerly.  This also makes the transport's
+    // first exchange (connection set-up, lazy allocations) happen outside any capture.
+    int rc;
+    if (c->halo_state == HALO_NONE) {
+      if ((rc = post_exchange(c, FLUID_PART_VELOCITY | FLUID_PART_DENSITY))) return rc;
+      c->halo_state = HALO_POSTED;
+    }
+    if (c->halo_state == HALO_POSTED) {
+      if ((rc = wait_exchange(c))) return rc;
+      c->halo_state = HALO_JOINED;
+    }
+    int batch = 1;
+    while (batch * 2 <= c->graph_steps && batch * 2 <= nsteps - s) batch *= 2;
+    const int key = state_of(c) | (c->advect_early ? 8 : 0) | (batch << 8);
+    auto it = c->comm_graphs.find(key);
+    if (it == c->comm_graphs.end()) {
+      GraphEntry ge;
+      const int state0 = state_of(c);
+      const bool early0 = c->advect_early;
+      const long long ex0 = c->comm_exchanges, by0 = c->comm_bytes;
+      HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
+      rc = FLUID_OK;
+      for (int b = 0; b < batch && !rc; ++b) rc = comm_step(c);
+      if (!rc && c->halo_state == HALO_POSTED) rc = wait_exchange(c);  // joins comm_stream back into the capture
+      const hipError_t e = hipStreamEndCapture(c->stream, &ge.graph);
+      ge.next_state = state_of(c);
+      ge.exchanges = c->comm_exchanges - ex0;
+      ge.bytes = c->comm_bytes - by0;
+      set_state(c, state0);
+      c->advect_early = early0;
+      c->halo_state = HALO_JOINED;
+      c->comm_exchanges = ex0;
+      c->comm_bytes = by0;
+      c->enq_rc = 0;
+      hipError_t ei = hipSuccess;
+      if (!rc && e == hipSuccess) ei = hipGraphInstantiate(&ge.exec, ge.graph, nullptr, nullptr, 0);
+      if (rc || e != hipSuccess || ei != hipSuccess) {
+        // this transport's calls (or this runtime) do not capture: launch everything eagerly from
+        // now on — nothing of the failed capture has run
+        snprintf(c->comm_note, sizeof c->comm_note, "graph capture given up (%s): %.100s",
+                 rc ? "enqueue" : e != hipSuccess ? hipGetErrorString(e) : hipGetErrorString(ei), rc ? c->err : "");
+        if (ge.graph) (void)hipGraphDestroy(ge.graph);
+        (void)hipGetLastError();
+        c->comm_graph = false;
+        continue;
+      }
+      it = c->comm_graphs.emplace(key, ge).first;
+    }
+    HIPCHK(c, hipGraphLaunch(it->second.exec, c->stream));
+    set_state(c, it->second.next_state);
+    c->advect_early = false;
+    c->halo_state = HALO_JOINED;
+    c->comm_exchanges += it->second.exchanges;
+    c->comm_bytes += it->second.bytes;
+    s += batch;
+  }
+  return FLUID_OK;
+}
+
+static int comm_attach_common(fluid_ctx *c, const Transport &t) {
+  HIPCHK(c, hipSetDevice(c->prm.device));
+  if (!c->comm_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+  if (!c->ev_ready) HIPCHK(c, hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
+  if (!c->ev_halo) HIPCHK(c, hipEventCreateWithFlags(&c->ev_halo, hipEventDisableTiming));
+  c->tr = t;
+  c->has_comm = true;
+  c->halo_state = HALO_NONE;
+  c->comm_graph = env_int("FLUID_COMM_GRAPH", 1) != 0;
+  c->early_advect = env_int("FLUID_SLAB_EARLY_ADVECT", 1) != 0;
+  c->comm_note[0] = 0;
+  return FLUID_OK;
+}
+
+static int comm_precheck(fluid_ctx *c) {
+  if (!c) return FLUID_E_INVALID;
+  if (!c->slab) return fail(c, FLUID_E_UNSUPPORTED, "a whole-domain context has no halos to exchange");
+  if (c->has_comm) return fail(c, FLUID_E_INVALID, "a transport is already attached (fluid_comm_detach first)");
+  return FLUID_OK;
+}
+
+int fluid_comm_unique_id(void *id_out, size_t id_bytes) {
+  char err[160];
+  if (!id_out) return FLUID_E_INVALID;
+  return rccl_unique_id(id_out, id_bytes, err, sizeof err) ? FLUID_OK : FLUID_E_COMM;
+}
+
+int fluid_comm_init_rccl(fluid_ctx *c, const void *id, size_t id_bytes) {
+  int rc = comm_precheck(c);
+  if (rc) return rc;
+  if (!id) return FLUID_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->prm.device));
+  Transport t;
+  char err[200];
+  if (!rccl_transport_init(id, id_bytes, c->prm.slab_rank, c->prm.slab_count, &t, err, sizeof err))
+    return fail(c, FLUID_E_COMM, "%s", err);
+  rc = comm_attach_common(c, t);
+  if (rc && t.destroy) t.destroy(t.user);
+  return rc;
+}
+
+int fluid_comm_attach_rccl(fluid_ctx *c, void *nccl_comm) {
+  int rc = comm_precheck(c);
+  if (rc) return rc;
+  if (!nccl_comm) return FLUID_E_INVALID;
+  Transport t;
+  char err[200];
+  if (!rccl_transport_from_comm(nccl_comm, c->prm.slab_rank, c->prm.slab_count, &t, err, sizeof err))
+    return fail(c, FLUID_E_COMM, "%s", err);
+  rc = comm_attach_common(c, t);
+  if (rc && t.destroy) t.destroy(t.user);
+  return rc;
+}
+
+int fluid_comm_attach(fluid_ctx *c, const fluid_transport *ft) {
+  int rc = comm_precheck(c);
+  if (rc) return rc;
+  if (!ft || !ft->group_start || !ft->send || !ft->recv || !ft->group_end) return FLUID_E_INVALID;
+  Transport t;
+  t.user = ft->user;
+  t.group_start = ft->group_start;
+  t.send = ft->send;
+  t.recv = ft->recv;
+  t.group_end = ft->group_end;
+  t.capturable = ft->capturable != 0;
+  t.name = "caller";
+  return comm_attach_common(c, t);
+}
+
+int fluid_comm_detach(fluid_ctx *c) {
+  if (!c) return FLUID_E_INVALID;
+  if (!c->has_comm) return FLUID_OK;
+  HIPCHK(c, hipSetDevice(c->prm.device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->comm_stream));
+  drop_graphs(c);
+  if (c->tr.destroy) c->tr.destroy(c->tr.user);
+  c->tr = Transport();
+  c->has_comm = false;
+  c->halo_state = HALO_NONE;
+  return FLUID_OK;
+}
+
+// Halo rows of the current state in place when the stream gets here (diagnostics across the
+// seams, a caller's own kernels): posts the exchange unless one is already posted, and waits.
+int fluid_comm_refresh(fluid_ctx *c) {
+  if (!c) return FLUID_E_INVALID;
+  if (!c->slab || !c->has_comm) return FLUID_E_UNSUPPORTED;
+  HIPCHK(c, hipSetDevice(c->prm.device));
+  int rc;
+  if (c->halo_state == HALO_NONE) {
+    if ((rc = post_exchange(c, FLUID_PART_VELOCITY | FLUID_PART_DENSITY))) return rc;
+    c->halo_state = HALO_POSTED;
+  }
+  if (c->halo_state == HALO_POSTED) {
+    if ((rc = wait_exchange(c))) return rc;
+    c->halo_state = HALO_JOINED;
+  }
+  return FLUID_OK;
+}
+
+int fluid_comm_selftest_rccl(int device, size_t bytes, int use_graph, char *msg, size_t msg_bytes) {
+  char local[256];
+  if (!msg || !msg_bytes) { msg = local; msg_bytes = sizeof local; }
+  if (!bytes) return FLUID_E_INVALID;
+  return rccl_selftest(device, bytes, use_graph != 0, msg, msg_bytes) ? FLUID_OK : FLUID_E_COMM;
+}
+
+int fluid_comm_info(const fluid_ctx *c, fluid_comm_stats *out) {
+  if (!c || !out) return FLUID_E_INVALID;
+  memset(out, 0, sizeof *out);
+  out->attached = c->has_comm;
+  out->capturable = c->has_comm && c->tr.capturable;
+  out->graph = c->has_comm && c->comm_graph && c->tr.capturable && !(c->prm.flags & FLUID_FLAG_NO_GRAPH);
+  out->graphs_built = (int)c->comm_graphs.size();
+  out->exchanges = c->comm_exchanges;
+  out->bytes_sent = c->comm_bytes;
+  snprintf(out->transport, sizeof out->transport, "%s", c->has_comm ? c->tr.name : "");
+  snprintf(out->note, sizeof out->note, "%s", c->comm_note);
+  return FLUID_OK;
 }
 
 void *fluid_stream(fluid_ctx *c) { return c ? (void *)c->stream : nullptr; }

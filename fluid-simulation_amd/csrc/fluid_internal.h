@@ -98,3 +98,24 @@ constexpr int DIAG_MAX_BLOCKS = 2048;
 struct DiagResult { float mx[DIAG_NMAX]; double sm[DIAG_NSUM]; };
 void launch_diagnostics(hipStream_t s, Geom g, int r0, int r1, const float2 *vel, const float4 *dens,
                         const float *p, const float *div, float *partial, DiagResult *out);
+
+// ---- halo transport (fluid_comm.hip; include/fluid.h fluid_comm_*) -----------------------------
+// One exchange = group_start, then a send and a recv per neighbour and field, then group_end, all
+// on one stream; every call returns 0 or a transport error (text from `error`).  Buffers are device
+// memory (the field rows themselves: halo blocks are whole rows, hence contiguous).
+struct Transport {
+  void *user = nullptr;
+  int (*group_start)(void *user) = nullptr;
+  int (*send)(void *user, const void *dev_src, size_t bytes, int peer, void *hip_stream) = nullptr;
+  int (*recv)(void *user, void *dev_dst, size_t bytes, int peer, void *hip_stream) = nullptr;
+  int (*group_end)(void *user, void *hip_stream) = nullptr;
+  const char *(*error)(void *user) = nullptr;   // may be null
+  void (*destroy)(void *user) = nullptr;        // may be null
+  bool capturable = false;                      // the calls may be made under stream capture
+  const char *name = "";
+};
+bool rccl_unique_id(void *out, size_t bytes, char *err, size_t errlen);
+bool rccl_transport_init(const void *id_bytes, size_t bytes, int rank, int nranks, Transport *out, char *err,
+                         size_t errlen);
+bool rccl_transport_from_comm(void *comm, int rank, int nranks, Transport *out, char *err, size_t errlen);
+bool rccl_selftest(int device, size_t bytes, bool use_graph, char *msg, size_t msglen);

@@ -91,6 +91,76 @@ class HaloExchanger:
         self.finish(tag, unpack)
 
 
+class HostStagedTransport:
+    """A caller-provided halo transport for fluid_comm_attach (include/fluid.h, fluid_transport):
+    the library's own slab step — exchange posted from C, overlapped with the interior launches —
+    with the bytes carried by torch.distributed through host memory.  For rehearsing the C path
+    where RCCL cannot run (several ranks on one GPU: tests, FLUID_BENCH_ONE_GPU); it blocks the
+    host in every exchange and is not capturable, so the library enqueues its steps directly.
+
+    send: wait for the stream (the rows are final), copy them to the host, post isend;
+    recv: post irecv; group_end: wait for all, copy the received rows into the halo rows on the
+    stream the library named, and wait for those copies (the staging tensors die with the call).
+    """
+
+    def __init__(self, group=None):
+        import ctypes as C
+        import torch
+        import torch.distributed as dist
+        from . import capi
+        self.torch, self.dist, self.group = torch, dist, group
+        hip = C.CDLL("libamdhip64.so.7")   # by SONAME: the copy this process already runs on
+        hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+        hip.hipMemcpyAsync.restype = C.c_int
+        hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+        hip.hipStreamSynchronize.restype = C.c_int
+        self.hip = hip
+        self.ops, self.recvs, self.exchanges = [], [], 0
+        self._cbs = (capi.TRANSPORT_GROUP_START(self._group_start), capi.TRANSPORT_SEND(self._send),
+                     capi.TRANSPORT_RECV(self._recv), capi.TRANSPORT_GROUP_END(self._group_end))
+        self.struct = capi.FluidTransport(None, *self._cbs, 0)
+
+    def _guard(self, fn, *a):
+        try:
+            return fn(*a) or 0
+        except Exception:   # an exception must not unwind through the C caller
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    def _group_start(self, user):
+        self.ops, self.recvs = [], []
+        return 0
+
+    def _send(self, user, src, nbytes, peer, stream):
+        def run():
+            t = self.torch.empty(nbytes, dtype=self.torch.uint8)
+            if self.hip.hipMemcpyAsync(t.data_ptr(), src, nbytes, 2, stream) or self.hip.hipStreamSynchronize(stream):
+                return 1
+            self.ops.append(self.dist.P2POp(self.dist.isend, t, peer, self.group))
+        return self._guard(run)
+
+    def _recv(self, user, dst, nbytes, peer, stream):
+        def run():
+            t = self.torch.empty(nbytes, dtype=self.torch.uint8)
+            self.ops.append(self.dist.P2POp(self.dist.irecv, t, peer, self.group))
+            self.recvs.append((t, dst, nbytes))
+        return self._guard(run)
+
+    def _group_end(self, user, stream):
+        def run():
+            for req in (self.dist.batch_isend_irecv(self.ops) if self.ops else []):
+                req.wait()
+            for t, dst, nbytes in self.recvs:
+                if self.hip.hipMemcpyAsync(dst, t.data_ptr(), nbytes, 1, stream):
+                    return 1
+            if self.hip.hipStreamSynchronize(stream):
+                return 1
+            self.ops, self.recvs = [], []
+            self.exchanges += 1
+        return self._guard(run)
+
+
 class SlabSim:
     """One rank's slab of a domain decomposed over ``world`` processes (one GPU each).
 
@@ -109,14 +179,27 @@ class SlabSim:
     (With FLUID_FLAG_UNFUSED the two stages are separate kernels: velocity halos then travel during
     the density advection, density halos during the next velocity part.)  Same messages, same
     results; only when they move differs.
+
+    ``transport``: who drives the exchange.
+      "torch"  (default; env FLUID_SLAB_TRANSPORT) this class, as described above: the step in parts
+               from Python, halos packed into staging tensors and moved by torch.distributed P2P;
+      "rccl"   the library itself (include/fluid.h, fluid_comm_*): ncclSend / ncclRecv straight
+               out of and into the field rows, posted from C on a second stream between the edge
+               and interior launches, whole steps replayed as hipGraphs; this class only makes
+               the communicator (unique id broadcast over ``group``) and calls fluid_step;
+      "staged" the same C path with :class:`HostStagedTransport` (rehearsal on one GPU).
     """
 
     def __init__(self, pkg, n: int, *, rank: int, world: int, device_index: int = 0, group=None,
-                 overlap: Optional[bool] = None, **params):
+                 overlap: Optional[bool] = None, transport: Optional[str] = None, **params):
         import os
         import torch
         self.pkg, self.rank, self.world = pkg, rank, world
         self.torch = torch
+        self.transport = transport or os.environ.get("FLUID_SLAB_TRANSPORT", "torch")
+        if self.transport not in ("torch", "rccl", "staged"):
+            raise ValueError(f"unknown slab transport {self.transport!r}")
+        self.in_library = self.transport != "torch" and world > 1
         torch.cuda.set_device(device_index)
         self.stream = torch.cuda.Stream(device=device_index)       # kernels, unpack
         # pack, transfers.  Normal priority, always: a high-priority second stream was tried in round 1
@@ -134,6 +217,20 @@ class SlabSim:
         self.split_tail = not (params.get("flags", 0) & pkg.FLAG_UNFUSED)
         # the interior rows of the next step's advection before its velocity halos are waited for
         self.early_advect = world > 1 and os.environ.get("FLUID_SLAB_EARLY_ADVECT", "1") != "0"
+        self._staged = None
+        if self.in_library:
+            import torch.distributed as dist
+            if self.transport == "rccl":
+                box = [self.sim.lib.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0, group=group)
+                self.sim.comm_init_rccl(box[0])          # collective: ncclCommInitRank
+            else:
+                self._staged = HostStagedTransport(group)
+                self.sim.comm_attach(self._staged.struct)
+
+    @property
+    def bytes_moved(self) -> int:
+        return self.sim.comm_info()["bytes_sent"] if self.in_library else self.ex.bytes_moved
 
     def _velocity_part(self, tail=True):
         """The velocity part on the compute stream (``tail=False``: without the gradient
@@ -181,11 +278,15 @@ class SlabSim:
 
     # -- the FluidSim interface ----------------------------------------------------------------
     def add_source(self, *a, **k):
-        self._discard_in_flight()  # halos already travelling would be stale after this
+        if not self.in_library:
+            self._discard_in_flight()  # halos already travelling would be stale after this
         self.sim.add_source(*a, **k)
 
     def step(self, nsteps: int = 1):
         sim, V, D = self.sim, self.V, self.D
+        if self.in_library:          # the library exchanges and overlaps by itself
+            sim.step(nsteps)
+            return
         if not self.overlap:
             for _ in range(nsteps):
                 with self.torch.cuda.stream(self.stream):
@@ -236,9 +337,12 @@ class SlabSim:
         then the ranks combine: maxima by all-reduce(MAX), dye sums by all-reduce(SUM)."""
         import torch.distributed as dist
         torch = self.torch
-        if not self.ex.in_flight(self.V):   # overlap mode has the next step's halos on the way already
-            self._start(self.V)
-        self._finish(self.V)
+        if self.in_library:
+            self.sim.comm_refresh()
+        else:
+            if not self.ex.in_flight(self.V):   # overlap mode has the next step's halos on the way already
+                self._start(self.V)
+            self._finish(self.V)
         d = self.sim.diagnostics()
         dev = self.ex.device if dist.get_backend(self.ex.group) == "nccl" else "cpu"
         keys = self.pkg.FluidDiag.MAX_KEYS
@@ -266,7 +370,8 @@ class SlabSim:
         return np.concatenate(parts, axis=0) if self.rank == 0 else None
 
     def close(self):
-        self._discard_in_flight()
+        if not self.in_library:
+            self._discard_in_flight()
         self.sim.sync()
         self.sim.close()
 

@@ -314,6 +314,75 @@ FLUID_API int fluid_halo_unpack_part(fluid_ctx *ctx, int dir, int part, const vo
 FLUID_API int fluid_halo_pack(fluid_ctx *ctx, int dir, void *dev_dst);
 FLUID_API int fluid_halo_unpack(fluid_ctx *ctx, int dir, const void *dev_src);
 
+/* ---- halo transport under the C ABI ------------------------------------------
+ *
+ * No counterpart in the reference (single GPU).  With a transport attached to a slab context,
+ * fluid_step(ctx, nsteps) IS the multi-GPU step: before each step the library exchanges the halo
+ * blocks itself (one group per step: halo_vel velocity rows and halo_dens density rows to and
+ * from each neighbour, sent from and received into the field rows directly — whole rows are
+ * contiguous, nothing is staged), on a second HIP stream, overlapped with compute: the last
+ * kernel of a step runs on the edge rows first, the exchange for the next step is posted, and
+ * the interior rows (and the interior rows of the next step's advection) are computed while the
+ * messages travel.  With a capturable transport (RCCL) whole steps — both streams and the
+ * send/recv calls — are captured as hipGraphs of up to 16 steps and replayed; if the capture is
+ * refused the steps are enqueued directly instead (fluid_comm_info reports which).  Results are
+ * bit-identical to the whole-domain run.  Contexts with pressure_groups exchange pressure rows
+ * between groups as well.
+ *
+ * The calls are collective in the SPMD sense: every slab makes the same fluid_* calls in the same
+ * order (fluid_add_source, fluid_reset and fluid_write invalidate halos already exchanged; the
+ * next fluid_step exchanges again).  Slab k talks to slabs k-1 and k+1 as ranks k-1 / k+1 of the
+ * transport.
+ *
+ *   fluid_comm_unique_id   ncclGetUniqueId: 128 bytes for rank 0 to hand to the others (any way)
+ *   fluid_comm_init_rccl   ncclCommInitRank(slab_count ranks, id, slab_rank) on the context's
+ *                          device; collective; the communicator is destroyed with the context
+ *   fluid_comm_attach_rccl an existing ncclComm_t whose rank / size are the slab's (caller-owned)
+ *   fluid_comm_attach      any other transport: four callbacks, each returning 0 or an error;
+ *                          one exchange = group_start, send + recv per neighbour and field,
+ *                          group_end; pointers are device memory; `hip_stream` is the stream the
+ *                          transfers must be ordered on (work enqueued on it before the call
+ *                          precedes them, work enqueued after group_end follows them); peers are
+ *                          slab ranks.  capturable != 0: the calls may be made under
+ *                          hipStreamBeginCapture and become graph nodes
+ *   fluid_comm_detach      drains both streams and drops the transport
+ *   fluid_comm_refresh     halo rows of the current state in place without stepping
+ * librccl is bound at run time (dlopen), so the library itself has no RCCL dependency. */
+#define FLUID_COMM_ID_BYTES 128
+typedef struct fluid_transport {
+  void *user;
+  int (*group_start)(void *user);
+  int (*send)(void *user, const void *dev_src, size_t bytes, int peer, void *hip_stream);
+  int (*recv)(void *user, void *dev_dst, size_t bytes, int peer, void *hip_stream);
+  int (*group_end)(void *user, void *hip_stream);
+  int capturable;
+} fluid_transport;
+typedef struct fluid_comm_stats {
+  int attached;          /* a transport is attached                                      */
+  int capturable;        /* it may be captured                                           */
+  int graph;             /* whole steps are replayed as hipGraphs (0: enqueued directly) */
+  int graphs_built;      /* graphs captured so far                                       */
+  long long exchanges;   /* halo exchanges posted so far                                 */
+  long long bytes_sent;  /* bytes sent so far                                            */
+  char transport[16];    /* "rccl" / "caller"                                            */
+  char note[160];        /* why graph capture was given up, if it was                    */
+} fluid_comm_stats;
+FLUID_API int fluid_comm_unique_id(void *id_out, size_t id_bytes);
+FLUID_API int fluid_comm_init_rccl(fluid_ctx *ctx, const void *id, size_t id_bytes);
+FLUID_API int fluid_comm_attach_rccl(fluid_ctx *ctx, void *nccl_comm);
+FLUID_API int fluid_comm_attach(fluid_ctx *ctx, const fluid_transport *t);
+FLUID_API int fluid_comm_detach(fluid_ctx *ctx);
+/* Collective: the halo rows of the CURRENT state in place when the context's stream gets to
+ * whatever is enqueued next (fluid_diagnostics across the seams, a caller's own kernels); posts
+ * the exchange unless the last fluid_step already did, and makes the stream wait for it. */
+FLUID_API int fluid_comm_refresh(fluid_ctx *ctx);
+FLUID_API int fluid_comm_info(const fluid_ctx *ctx, fluid_comm_stats *out);
+/* One-GPU check of the RCCL binding (a slab context on a single GPU has no neighbour to talk to):
+ * a one-rank communicator on `device` sends `bytes` bytes to itself through the same calls the
+ * slab step makes — eagerly, then (use_graph) captured as a hipGraph and replayed twice — and the
+ * received bytes are verified on the host.  msg (may be NULL) receives what was done / what failed. */
+FLUID_API int fluid_comm_selftest_rccl(int device, size_t bytes, int use_graph, char *msg, size_t msg_bytes);
+
 /* ---- caller-provided stream ------------------------------------------------ */
 
 /* The context's hipStream_t (as void*).  fluid_set_stream makes the context

@@ -18,11 +18,12 @@ def main():
     backend, n, J, steps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
     overlap = bool(int(sys.argv[5]))
     groups = int(sys.argv[6]) if len(sys.argv) > 6 else 0
+    transport = sys.argv[7] if len(sys.argv) > 7 else "torch"   # "staged": the exchange posted by the library itself
     dist.init_process_group(backend, rank=rank, world_size=world)
     pkg = fluid_amd_loader.load()
     from fluid_simulation_amd.slab import SlabSim
     sim = SlabSim(pkg, n, rank=rank, world=world, device_index=0, pressure_iters=J, halo_rows=2,
-                  overlap=overlap, pressure_groups=groups)
+                  overlap=overlap, pressure_groups=groups, transport=transport)
     ss = pkg.SplatStream()
     for s in range(steps):
         if s % 2 == 0:
@@ -51,6 +52,11 @@ def main():
             want = whole.read(f)
             assert got.shape == want.shape
             assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"field {f} differs"
+    if transport != "torch":
+        info = sim.sim.comm_info()
+        assert info["attached"] and info["exchanges"] >= steps + 4 and info["bytes_sent"] > 0, info
+        assert not info["graph"] and info["transport"] == "caller", info   # host-staged: not capturable
+    sim.close()
     dist.barrier()
     dist.destroy_process_group()
     print(f"rank {rank} ok")

@@ -345,6 +345,51 @@ def test_slabsim_multiprocess_on_one_gpu(world, overlap):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world,n,J,groups", [(2, 512, 10, 0), (4, 512, 10, 0), (3, 384, 30, 3)])
+def test_library_driven_exchange_multiprocess_on_one_gpu(world, n, J, groups):
+    """fluid_step on slab contexts with a transport attached (fluid_comm_attach): the library posts
+    the exchange itself, straight out of and into the field rows, between the edge and interior
+    launches of the last kernel, and runs the interior advection ahead of the halos.  One process
+    per slab sharing GPU 0; the bytes travel through HostStagedTransport (gloo) because RCCL
+    refuses two ranks per device.  Gathered result == whole-domain context, bit for bit, through
+    splats between steps (halos invalidated), several steps per call and diagnostics."""
+    port = free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), GLOO_SOCKET_IFNAME="lo")
+        procs.append(subprocess.Popen(
+            [sys.executable, os.path.join(ROOT, "tests", "slab_gpu_worker.py"), "gloo", str(n), str(J), "6", "1",
+             str(groups), "staged"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out)
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} failed:\n{out[-3000:]}"
+
+
+@pytest.mark.gpu
+def test_rccl_binding_on_one_gpu(pkg, hip):
+    """The RCCL leg of the transport on the one GPU a test box has: a one-rank communicator sends
+    to itself through the calls the slab step makes (ncclGroupStart / ncclSend / ncclRecv /
+    ncclGroupEnd bound by dlopen), eagerly and as a captured hipGraph replayed twice."""
+    msg = hip.comm_selftest_rccl(0, 3 << 20, True)
+    print(msg)
+    assert "2 graph replays" in msg
+    assert len(hip.comm_unique_id()) == pkg.COMM_ID_BYTES
+    whole = pkg.FluidSim(256, lib=hip)
+    with pytest.raises(pkg.FluidError):
+        whole.comm_init_rccl(hip.comm_unique_id())   # a whole-domain context has no halos
+    whole.close()
+
+
+@pytest.mark.gpu
 def test_step_parts_equal_whole_step(pkg, hip):
     """fluid_step(1) == fluid_step_part(VELOCITY) + fluid_step_part(DENSITY), whole-domain and slab
     contexts alike (the slab variant also moves the two fields' halos separately)."""
