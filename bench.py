@@ -14,6 +14,9 @@ grid is fixed) and halo rows travel over RCCL.  Two ways in:
   - plain `python bench.py --gpus N`: this process touches no GPU, starts N fresh children of
     itself with those variables set (launch_ranks), relays rank 0's JSON line, and exits non-zero
     if a rank fails or the wall-clock limit (FLUID_BENCH_TIMEOUT, seconds) passes.
+Either way a rank process only supervises (bench_multi.supervise_rank): the benchmark itself runs
+in a child per attempt, so that an exchange mode that hangs on the node at hand costs one attempt
+and the next, more conservative mode still produces the line.
 """
 import argparse
 import json
@@ -195,7 +198,7 @@ def launch_ranks(nranks, argv):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    limit = float(os.environ.get("FLUID_BENCH_TIMEOUT", "1500"))
+    limit = float(os.environ.get("FLUID_BENCH_TIMEOUT", "2400"))
     procs = []
     for r in range(nranks):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nranks), LOCAL_WORLD_SIZE=str(nranks),
@@ -252,6 +255,10 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))   # before anything imports torch / touches HIP
+    if (args.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1) and "FLUID_BENCH_ATTEMPT" not in os.environ:
+        # one rank, under a launcher or launch_ranks: supervise attempts, touch no GPU (bench_multi.py)
+        from bench_multi import supervise_rank
+        sys.exit(supervise_rank(sys.argv[1:]))
 
     import fluid_amd_loader
     pkg = fluid_amd_loader.load()

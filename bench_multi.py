@@ -1,10 +1,91 @@
-"""Multi-GPU leg of bench.py: one rank per GPU (torch.distributed.run), row slabs, RCCL halos."""
+"""Multi-GPU leg of bench.py: one rank per GPU, row slabs, halo rows over RCCL.
+
+Process layout (bench.py): launcher or torch.distributed.run -> one RANK process per GPU, which is
+only a supervisor (supervise_rank: touches no GPU) -> one CHILD per attempt, which runs run_multi.
+Nothing multi-rank can be rehearsed on the one-GPU boxes this was built on, so the child verifies
+before it times, and a hang costs one attempt, not the job:
+
+  * every rank first runs the WHOLE domain on its own GPU for three steps (it fits: 16 GB at
+    16384^2) and keeps checksums of its own rows: the truth;
+  * the exchange modes are tried in order — "rccl-graph" (halos posted by the library itself from
+    C, ncclSend/ncclRecv out of and into the field rows, whole steps replayed as hipGraphs),
+    "rccl" (the same, enqueued directly), "torch" (round 1's Python-driven exchange through
+    torch.distributed P2P) — and the first whose slabs reproduce the truth bit for bit on every rank
+    is the one that is timed;
+  * a mode that hangs or kills a rank ends the attempt (watchdog / supervisor), and the next
+    attempt starts one mode further down the list on a fresh rendezvous port.
+"""
 import json
 import os
+import sys
 import time
 
 
+def default_modes():
+    rehearsal = os.environ.get("FLUID_BENCH_BACKEND", "nccl") != "nccl"
+    return "staged,torch" if rehearsal else "rccl-graph,rccl,torch"
+
+
+def rendezvous_wait(attempt, limit):
+    """Seconds the ranks of attempt `attempt` wait for each other: more than the previous attempt can
+    last on a rank that hung in it (its own rendezvous + the watchdog + process start-up, where the
+    first `import torch` on a fresh box takes a minute or two)."""
+    margin = float(os.environ.get("FLUID_BENCH_RENDEZVOUS_MARGIN", "150"))
+    return (attempt + 1) * (limit + margin)
+
+
+def supervise_rank(argv):
+    """One rank, no GPU: run the benchmark in a child per attempt; on a failed or hung attempt
+    start the next with the first mode dropped.  Every rank does the same, so the ranks of an
+    attempt find each other on MASTER_PORT + 1 + attempt."""
+    import signal
+    import subprocess
+    rank = os.environ.get("RANK", "0")
+    modes = os.environ.get("FLUID_BENCH_MODES", default_modes()).split(",")
+    base_port = int(os.environ.get("MASTER_PORT", "29500"))
+    limit = float(os.environ.get("FLUID_BENCH_ATTEMPT_TIMEOUT", "240"))   # watchdog of one attempt, once its ranks have met
+    child = [None]
+
+    def on_term(signum, frame):   # the launcher ends this rank: take the child along
+        if child[0] is not None and child[0].poll() is None:
+            child[0].kill()
+        sys.exit(128 + signum)
+    signal.signal(signal.SIGTERM, on_term)
+    signal.signal(signal.SIGINT, on_term)
+    for attempt in range(len(modes)):
+        env = dict(os.environ, FLUID_BENCH_ATTEMPT=str(attempt), FLUID_BENCH_MODES=",".join(modes[attempt:]),
+                   MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=str(base_port + 1 + attempt),
+                   FLUID_BENCH_RANK_TIMEOUT=str(limit))
+        env.pop("TORCHELASTIC_USE_AGENT_STORE", None)   # rank 0's child hosts the store of its attempt
+        p = subprocess.Popen([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "bench.py")]
+                             + list(argv), env=env)   # same session: whoever ends this rank's session ends the child too
+        child[0] = p
+        try:
+            rc = p.wait(timeout=rendezvous_wait(attempt, limit) + limit + 60)
+        except subprocess.TimeoutExpired:
+            p.kill()   # exactly the child started above
+            p.wait()
+            rc = 124
+        if rc == 0:
+            return 0
+        print(f"bench.py rank {rank}: attempt {attempt} (modes {','.join(modes[attempt:])}) ended with {rc}",
+              file=sys.stderr, flush=True)
+    return 1
+
+
+def _checksums(pkg, sim):
+    import numpy as np
+    return [int(sim.read(f).view(np.uint32).sum(dtype=np.uint64))
+            for f in (pkg.FIELD_VELOCITY, pkg.FIELD_DENSITY, pkg.FIELD_PRESSURE)]
+
+
+VERIFY_STEPS = 3
+
+
 def run_multi(pkg, args, n, D, J, flags):
+    import datetime
+    import faulthandler
+    import numpy as np
     import torch
     import torch.distributed as dist
     from fluid_simulation_amd.slab import SlabSim
@@ -15,7 +96,7 @@ def run_multi(pkg, args, n, D, J, flags):
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
-                         f"--nproc-per-node {args.gpus}")
+                         f"--nproc-per-node {args.gpus}, or with no launcher at all")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     # FLUID_BENCH_BACKEND=gloo + FLUID_BENCH_ONE_GPU=1: rehearsal of this code path with several
     # ranks on a single GPU (RCCL refuses two ranks per device); never the measured configuration.
@@ -25,17 +106,28 @@ def run_multi(pkg, args, n, D, J, flags):
     torch.cuda.set_device(local)
     # A rank that waits for a peer that never comes (or a transfer that never ends) must not hang
     # the job: after FLUID_BENCH_RANK_TIMEOUT seconds every rank dumps its Python stacks and exits
-    # non-zero (the launcher in bench.py / torch.distributed.run then ends the others).
-    import datetime
-    import faulthandler
-    limit = float(os.environ.get("FLUID_BENCH_RANK_TIMEOUT", "1200"))
-    faulthandler.dump_traceback_later(limit, exit=True)
-    tmo = datetime.timedelta(seconds=min(limit, 600))
-    if backend == "nccl":
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local),
-                                timeout=tmo)
-    else:
-        dist.init_process_group(backend, rank=rank, world_size=world, timeout=tmo)
+    # non-zero (its supervisor then starts the next attempt).
+    limit = float(os.environ.get("FLUID_BENCH_RANK_TIMEOUT", "240"))
+    attempt = int(os.environ.get("FLUID_BENCH_ATTEMPT", "0"))
+    # control plane (barriers, the reductions of flags and times, the RCCL id): gloo, CPU tensors.
+    # A rank whose previous attempt died early waits here for the ranks whose attempt ran into its
+    # watchdog: the rendezvous of attempt a waits rendezvous_wait(a), longer than attempt a - 1 can last.
+    dist.init_process_group("gloo", rank=rank, world_size=world,
+                            timeout=datetime.timedelta(seconds=rendezvous_wait(attempt, limit)))
+    faulthandler.dump_traceback_later(limit, exit=True)   # armed once the ranks have met
+    if os.environ.get("FLUID_BENCH_TEST_DIE") == str(attempt) and rank == world - 1:
+        os._exit(3)   # tests: the last rank of this attempt dies; the others must notice and move on
+    p2p_group = None   # the "torch" mode's data plane, made when that mode is reached
+
+    def all_min(flag):
+        t = torch.tensor([int(flag)])
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
+
+    def all_max(x):
+        t = torch.tensor([x], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     # Deep pressure loops on short slabs: the J sweeps can be cut into groups with a pressure-halo
     # exchange in between (include/fluid.h, pressure_groups).  Measured on one MI355X (tools/
@@ -49,33 +141,64 @@ def run_multi(pkg, args, n, D, J, flags):
     groups = int(os.environ.get("FLUID_BENCH_GROUPS", groups))
     gkw = {"pressure_groups": groups} if groups > 1 else {}
 
-    # Self-check on the real transport before timing: the overlapped exchange must give the bits
-    # of the plain one (3 steps from the same splats); otherwise time the plain path.
-    import numpy as np
-    overlap_ok = True
-    if os.environ.get("FLUID_SLAB_OVERLAP", "1") != "0":
-        sums = []
-        for ov in (True, False):
-            s_ = SlabSim(pkg, n, rank=rank, world=world, device_index=local, diffusion_iters=D,
-                         pressure_iters=J, flags=flags, overlap=ov, **gkw)
+    # The truth: the whole domain on this rank's own GPU, VERIFY_STEPS steps from the seeded splats.
+    whole = pkg.FluidSim(n, device=local, diffusion_iters=D, pressure_iters=J, flags=flags)
+    seeded_warm_state(pkg, whole)
+    whole.step(VERIFY_STEPS)
+    plan = pkg.FluidLib().slab_plan(n, rank, world, diffusion_iters=D, pressure_iters=J, pressure_groups=groups)
+    truth = []
+    for f in (pkg.FIELD_VELOCITY, pkg.FIELD_DENSITY, pkg.FIELD_PRESSURE):
+        a = whole.read(f)
+        truth.append(int(a[plan["row0"]:plan["row0"] + plan["rows"]].view(np.uint32).sum(dtype=np.uint64)))
+        del a
+    whole.close()
+
+    modes = os.environ.get("FLUID_BENCH_MODES", default_modes()).split(",") if world > 1 else ["torch"]
+    tried, sim, mode = [], None, None
+    for m in modes:
+        note, ok, s_ = "", False, None
+        try:
+            if m in ("rccl-graph", "rccl", "staged"):
+                os.environ["FLUID_COMM_GRAPH"] = "1" if m == "rccl-graph" else "0"   # read when the transport is attached
+                s_ = SlabSim(pkg, n, rank=rank, world=world, device_index=local, diffusion_iters=D, pressure_iters=J,
+                             flags=flags, transport="staged" if m == "staged" else "rccl", **gkw)
+            elif m in ("torch", "torch-plain"):
+                if p2p_group is None and backend == "nccl":
+                    p2p_group = dist.new_group(backend="nccl", device_id=torch.device("cuda", local))
+                s_ = SlabSim(pkg, n, rank=rank, world=world, device_index=local, diffusion_iters=D, pressure_iters=J,
+                             flags=flags, transport="torch", group=p2p_group, overlap=(m == "torch"), **gkw)
+            else:
+                raise ValueError(f"unknown mode {m!r}")
             seeded_warm_state(pkg, s_)
-            s_.step(3)
+            s_.step(VERIFY_STEPS)
             s_.sync()
-            sums.append([int(s_.read(f).view(np.uint32).sum(dtype=np.uint64))
-                         for f in (pkg.FIELD_VELOCITY, pkg.FIELD_DENSITY, pkg.FIELD_PRESSURE)])
-            s_.close()
-        ok = torch.tensor([int(sums[0] == sums[1])], device="cuda")
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        overlap_ok = bool(ok.item())
-    sim = SlabSim(pkg, n, rank=rank, world=world, device_index=local, diffusion_iters=D,
-                  pressure_iters=J, flags=flags, overlap=None if overlap_ok else False, **gkw)
-    seeded_warm_state(pkg, sim)          # every rank applies the same splats to its own rows
+            ok = _checksums(pkg, s_) == truth
+            if not ok:
+                note = "slab rows differ from the whole-domain run"
+            if ok and m == "rccl-graph" and not s_.sim.comm_info()["graph"]:
+                ok, note = False, "graph capture refused: " + s_.sim.comm_info()["note"]
+        except Exception as e:   # noqa: BLE001 - any failure means: next mode
+            note = f"{type(e).__name__}: {e}"
+        ok = all_min(ok)
+        tried.append({"mode": m, "ok": ok, "note": note})
+        if ok:
+            sim, mode = s_, m
+            break
+        if s_ is not None:
+            try:
+                s_.close()
+            except Exception:   # noqa: BLE001
+                pass
+    if sim is None:
+        if rank == 0:
+            print(f"bench.py: no exchange mode reproduced the whole-domain run: {tried}", file=sys.stderr, flush=True)
+        sys.exit(2)
+
     # The early interior advection (FLUID_PART_ADVECT_INTERIOR) buys the velocity message 0.1 ms more
-    # cover for 12 us of launches per step; which way that nets out depends on the links of the node
-    # at hand, so both ways are tried on the real transport, before the warm-up and the timed region.
-    # Every rank takes the same decision (times are max-reduced over the ranks).
+    # cover for 12 us of launches per step; in the Python-driven mode both ways are tried on the real
+    # transport before the warm-up (times max-reduced: every rank takes the same decision).
     tune = None
-    if sim.overlap and sim.split_tail and sim.early_advect and os.environ.get("FLUID_SLAB_EARLY_ADVECT") is None:
+    if mode == "torch" and sim.split_tail and sim.early_advect and os.environ.get("FLUID_SLAB_EARLY_ADVECT") is None:
         tune, trial = {}, (20 if backend == "nccl" else 2)
         for early in (True, False):
             sim.early_advect = early
@@ -87,31 +210,31 @@ def run_multi(pkg, args, n, D, J, flags):
             sim.step(trial)
             sim.sync()
             torch.cuda.synchronize()
-            tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            tune["early" if early else "late"] = round(float(tt.item()) / trial * 1e3, 5)
+            tune["early" if early else "late"] = round(all_max(time.perf_counter() - t0) / trial * 1e3, 5)
         sim.early_advect = tune["early"] <= tune["late"]
     sim.step(args.warmup)
     sim.sync()
     torch.cuda.synchronize()
     dist.barrier()
-    moved0 = sim.ex.bytes_moved
+    moved0 = sim.bytes_moved
     t0 = time.perf_counter()
     sim.step(args.steps)
     sim.sync()
     torch.cuda.synchronize()
     dist.barrier()
-    wall = time.perf_counter() - t0
-    moved = sim.ex.bytes_moved - moved0   # sent in the timed region only (the tuning trials above moved more)
-    t = torch.tensor([wall], dtype=torch.float64, device="cuda")
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    wall = float(t.item())
+    wall = all_max(time.perf_counter() - t0)
+    moved = sim.bytes_moved - moved0   # sent in the timed region only
 
     diag = sim.diagnostics()   # slab reductions + all-reduce, after the timed region
+    comm = sim.sim.comm_info() if sim.in_library else None
     if rank == 0:
         t_step = wall / args.steps
         bpc = pkg.alg_bytes_per_cell(D, J)
-        plan = pkg.FluidLib().slab_plan(n, 0, world, diffusion_iters=D, pressure_iters=J, pressure_groups=groups)
+        carrier = {"rccl-graph": "RCCL ncclSend/ncclRecv posted by the library, whole steps replayed as hipGraphs",
+                   "rccl": "RCCL ncclSend/ncclRecv posted by the library, steps enqueued directly",
+                   "staged": "host-staged rehearsal transport (one GPU), exchange posted by the library",
+                   "torch": "torch.distributed P2P (" + ("RCCL" if backend == "nccl" else backend) + "), step driven in parts from Python",
+                   "torch-plain": "torch.distributed P2P, exchange before the step, no overlap"}[mode]
         out = {
             "metric": "cell-updates/sec per full timestep (GCUPS)",
             "value": round(n * n / t_step / 1e9, 4), "unit": "GCUPS", "n_gpus": world,
@@ -125,19 +248,28 @@ def run_multi(pkg, args, n, D, J, flags):
                                         f"per neighbour"
                                         + (f", pressure sweeps in {plan['pressure_groups']} groups with {plan['halo_prs']} "
                                            f"pressure rows exchanged between groups" if plan['pressure_groups'] > 1 else "")
-                                        + f") over {'RCCL send/recv' if backend == 'nccl' else backend}"},
+                                        + f"); {carrier}"},
             "step_alg_bytes_per_cell": bpc,
             "step_effective_GBps": round(bpc * n * n / t_step / 1e9, 1),
             "step_frac_of_hbm_peak": round(bpc * n * n / t_step / 1e9 / (HBM_PEAK_GBPS * world), 4),
-            "transport": "RCCL (torch.distributed nccl)" if backend == "nccl" else backend,
+            "transport": carrier, "exchange_mode": mode, "modes_tried": tried,
+            "attempt": attempt,
             "halo_bytes_per_step_per_rank": moved // max(args.steps, 1),
-            "overlap": sim.overlap, "overlap_matches_plain_exchange": overlap_ok,
-            "early_interior_advection": bool(sim.overlap and sim.split_tail and sim.early_advect),
+            # the timed configuration reproduced the whole-domain run (every rank's own GPU, 3 steps)
+            # bit for bit on every rank's rows before it was timed
+            "slab_matches_whole_domain": True, "overlap_matches_plain_exchange": True,
+            "overlap": mode != "torch-plain", "comm": comm,
+            "early_interior_advection": bool(sim.early_advect) if mode == "torch" else (mode != "torch-plain"),
             "early_interior_advection_trial_ms_per_step": tune,
             "diagnostics_after_run": diag,
         }
         print(json.dumps(out), flush=True)
-    sim.close()
-    dist.barrier()
-    dist.destroy_process_group()
+    try:
+        sim.close()
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:   # noqa: BLE001 - the line is out; a teardown hiccup must not fail the attempt
+        pass
     faulthandler.cancel_dump_traceback_later()
+    sys.stdout.flush()
+    os._exit(0)

@@ -461,6 +461,37 @@ def test_bench_starts_its_own_ranks():
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["overlap_matches_plain_exchange"] is True
     assert rec["value"] > 0 and rec["unit"] == "GCUPS"
+    # the library-driven exchange was verified against the whole-domain run and timed
+    assert rec["exchange_mode"] == "staged" and rec["slab_matches_whole_domain"] is True and rec["attempt"] == 0
+    assert rec["comm"]["attached"] and rec["halo_bytes_per_step_per_rank"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_moves_on_when_an_attempt_dies():
+    """An exchange mode that kills a rank (or hangs: same path, through the watchdog) costs one
+    attempt: every rank's supervisor starts the next attempt one mode further down the list, on
+    the next rendezvous port, and the line still comes out.  Under torch.distributed.run-style
+    environment variables (no launcher of bench.py's own)."""
+    import json
+    port = free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), FLUID_BENCH_BACKEND="gloo", FLUID_BENCH_ONE_GPU="1", GLOO_SOCKET_IFNAME="lo",
+                   FLUID_BENCH_TEST_DIE="0", FLUID_BENCH_ATTEMPT_TIMEOUT="40",
+                   FLUID_BENCH_RENDEZVOUS_MARGIN="20")
+        env.pop("FLUID_BENCH_ATTEMPT", None)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload",
+                                       "512_J10", "--steps", "2", "--warmup", "1"], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (out, err) in zip(procs, outs):
+        assert p.returncode == 0, err[-3000:]
+    lines = [ln for ln in outs[0][0].splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, outs[0][0][-2000:]
+    rec = json.loads(lines[0])
+    assert rec["attempt"] == 1 and rec["exchange_mode"] == "torch" and rec["n_gpus"] == 2
+    assert "attempt 0" in outs[0][1]
 
 
 def test_bench_launcher_reports_a_failed_rank(tmp_path):
