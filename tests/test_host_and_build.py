@@ -109,3 +109,73 @@ def test_c_host_driver_matches_oracle(pkg, oracle, tmp_path):
         got = np.fromfile(f"{prefix}.{name}.f32", dtype=np.float32).reshape(ref.read(fid).shape)
         e = rel_err(got, ref.read(fid))
         assert e <= 1e-5, (name, e)
+
+
+EVENTS = [
+    {"frame": 0, "type": "down", "x": 100, "y": 200},
+    {"frame": 0, "type": "move", "x": 112, "y": 190},      # force (12, +10): y flipped, kernel.cu:872-873
+    {"frame": 1, "type": "move", "x": 140, "y": 215},
+    {"frame": 2, "type": "key", "key": "3"},               # green dye, kernel.cu:842-845
+    {"frame": 2, "type": "move", "x": 104, "y": 205},      # delta from the LAST event
+    {"frame": 4, "type": "key", "key": "v"},               # velocity view, kernel.cu:826-828
+    {"frame": 5, "type": "move", "x": 99, "y": 170},
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt", ["json", "lines"])
+def test_c_host_replays_a_session_and_writes_the_frame(pkg, hip, oracle, tmp_path, fmt):
+    """SURVEY.md 8f rows 2 and 3 in the C host: `fluid_headless --replay --view --ppm/--pfm` converts
+    recorded input like mouseClick / mouseMove / keyUp + addForce (kernel.cu:813-878, :687-690) and
+    writes the frame visualizationStep() would draw (:389-431, :710-756).  Checked against the
+    oracle driven by the same events (fields <= 1e-5: expf only), against the HIP library driven
+    from Python (same bits), and the written float frame against the view mapping of those bits."""
+    exe = os.path.join(ROOT, "host", "fluid_headless")
+    n, frames, W, H = 128, 8, 500, 300
+    evfile = tmp_path / ("events." + fmt)
+    if fmt == "json":
+        evfile.write_text(json.dumps(EVENTS))
+    else:
+        evfile.write_text("# frame type args\n" + "".join(
+            f"{e['frame']} {e['type']} " + (str(e['key']) if e['type'] == 'key' else f"{e['x']} {e['y']}") + "\n"
+            for e in EVENTS))
+    prefix, ppm, pfm = str(tmp_path / "dump"), str(tmp_path / "f.ppm"), str(tmp_path / "f.pfm")
+    res = subprocess.run([exe, "--n", str(n), "--replay", str(evfile), "--frames", str(frames), "--window", str(W), str(H),
+                          "--ppm", ppm, "--pfm", pfm, "--dump", prefix], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = json.loads(res.stdout.strip().splitlines()[-1])
+    assert line == {"n": n, "frames": frames, "events": len(EVENTS), "view": "v"}   # the session's 'v' key chose the view
+    ref = pkg.FluidSim(n, lib=oracle)
+    gpu = pkg.FluidSim(n, lib=hip)
+    for sim in (ref, gpu):
+        pkg.replay(sim, [e for e in EVENTS if not (e["type"] == "key" and e["key"] in "dvp")], frames, width=W, height=H)
+    got = {}
+    for name, fid in (("velocity", pkg.FIELD_VELOCITY), ("density", pkg.FIELD_DENSITY), ("pressure", pkg.FIELD_PRESSURE)):
+        got[name] = np.fromfile(f"{prefix}.{name}.f32", dtype=np.float32).reshape(ref.read(fid).shape)
+        assert float(np.abs(got[name]).max()) > 0
+        assert rel_err(got[name], ref.read(fid)) <= 1e-5, name
+        assert np.array_equal(got[name].view(np.uint32), gpu.read(fid).view(np.uint32)), name
+    # the frame: velocity view of the final state, window W x H over an n x n grid
+    raw = open(pfm, "rb").read()
+    head = b"PF\n%d %d\n-1.0\n" % (W, H)
+    assert raw.startswith(head)
+    img = np.frombuffer(raw[len(head):], "<f4").reshape(H, W, 3)
+    want = np.zeros((H, W, 3), np.float32)
+    want[:n, :n] = pkg.viz.velocity_image(got["velocity"])[:H, :W, :3]     # (1 + v) / 2, 0; beyond the grid: never written
+    assert np.array_equal(img.view(np.uint32), want.view(np.uint32))
+    praw = open(ppm, "rb").read()
+    phead = b"P6\n%d %d\n255\n" % (W, H)
+    assert praw.startswith(phead) and len(praw) == len(phead) + 3 * W * H
+    pix = np.frombuffer(praw[len(phead):], np.uint8).reshape(H, W, 3)[::-1]   # top row first in the file
+    assert np.array_equal(pix, (np.clip(want, 0, 1) * np.float32(255.0) + np.float32(0.5)).astype(np.uint8))
+    assert np.abs(rel_err(img[:n, :n], pkg.viz.velocity_image(ref.read(pkg.FIELD_VELOCITY))[..., :3])) <= 1e-5
+
+
+def test_c_host_rejects_bad_command_lines():
+    exe = os.path.join(ROOT, "host", "fluid_headless")
+    r = subprocess.run([exe, "--slab-rank", "0", "--slab-count", "2"], capture_output=True, text=True)
+    assert r.returncode == 2 and "--comm-file" in r.stderr
+    r = subprocess.run([exe, "--view", "x"], capture_output=True, text=True)
+    assert r.returncode == 2
+    r = subprocess.run([exe, "--bogus"], capture_output=True, text=True)
+    assert r.returncode == 2
