@@ -42,7 +42,7 @@ class FluidParams(C.Structure):
         ("n", C.c_int), ("diffusion_iters", C.c_int), ("pressure_iters", C.c_int),
         ("dt", C.c_float), ("viscosity", C.c_float), ("splat_radius", C.c_float),
         ("device", C.c_int), ("flags", C.c_uint), ("slab_rank", C.c_int), ("slab_count", C.c_int),
-        ("halo_rows", C.c_int), ("pressure_groups", C.c_int), ("reserved", C.c_int * 4),
+        ("halo_rows", C.c_int), ("pressure_groups", C.c_int), ("ny", C.c_int), ("reserved", C.c_int * 3),
     ]
 
 
@@ -196,11 +196,12 @@ class FluidLib:
         return msg.value.decode()
 
     def slab_plan(self, n, slab_rank, slab_count, *, diffusion_iters=None, pressure_iters=None,
-                  halo_rows=0, pressure_groups=0) -> dict:
+                  halo_rows=0, pressure_groups=0, ny=0) -> dict:
         """fluid_slab_plan: pure host arithmetic, needs no GPU."""
         p = self.default_params()
         p.n, p.slab_rank, p.slab_count, p.halo_rows = n, slab_rank, slab_count, halo_rows
         p.pressure_groups = pressure_groups
+        p.ny = ny
         if diffusion_iters is not None:
             p.diffusion_iters = diffusion_iters
         if pressure_iters is not None:
@@ -247,7 +248,7 @@ class FluidSim:
                  pressure_iters: Optional[int] = None, dt: Optional[float] = None,
                  viscosity: Optional[float] = None, splat_radius: Optional[float] = None,
                  device: int = 0, flags: int = 0, slab_rank: int = 0, slab_count: int = 0,
-                 halo_rows: int = 0, pressure_groups: int = 0, lib: Optional[FluidLib] = None):
+                 halo_rows: int = 0, pressure_groups: int = 0, ny: int = 0, lib: Optional[FluidLib] = None):
         self.lib = lib or _get_default_lib()
         p = self.lib.default_params()
         if n is not None:
@@ -265,6 +266,7 @@ class FluidSim:
         p.device, p.flags = device, flags
         p.slab_rank, p.slab_count, p.halo_rows = slab_rank, slab_count, halo_rows
         p.pressure_groups = pressure_groups
+        p.ny = ny   # rows; 0 = n (square, the reference's case); n is then the number of columns
         self.params = p
         self._h = C.c_void_p()
         rc = self.lib.dll.fluid_init(C.byref(self._h), C.byref(p))
@@ -279,7 +281,7 @@ class FluidSim:
         if slab_count > 1 and pressure_groups > 1:
             self.pressure_groups = self.lib.slab_plan(
                 self.n, slab_rank, slab_count, diffusion_iters=p.diffusion_iters, pressure_iters=p.pressure_iters,
-                halo_rows=halo_rows, pressure_groups=pressure_groups)["pressure_groups"]
+                halo_rows=halo_rows, pressure_groups=pressure_groups, ny=ny)["pressure_groups"]
 
     # -- plumbing ---------------------------------------------------------------
     def _chk(self, rc: int, what: str):

@@ -660,18 +660,20 @@ int fluid_default_params(fluid_params *p) {
 int fluid_slab_plan(const fluid_params *p, fluid_slab_info *out) {
   if (!p || !out) return FLUID_E_INVALID;
   if (p->n < 4 || p->diffusion_iters < 0 || p->pressure_iters < 0) return FLUID_E_INVALID;
+  if (p->ny != 0 && p->ny < 4) return FLUID_E_INVALID;
+  const int ny = p->ny ? p->ny : p->n;  // rows of the whole grid (square unless fluid_params.ny says otherwise)
   memset(out, 0, sizeof *out);
   out->n = p->n;
   if (p->slab_count <= 1) {
-    out->rows = p->n;
-    out->store_rows = p->n;
+    out->rows = ny;
+    out->store_rows = ny;
     out->pressure_groups = 1;
     return FLUID_OK;
   }
   if (p->slab_rank < 0 || p->slab_rank >= p->slab_count) return FLUID_E_INVALID;
   const int a = p->halo_rows > 0 ? p->halo_rows : 8;
-  out->row0 = (int)((long long)p->n * p->slab_rank / p->slab_count);
-  const int row1 = (int)((long long)p->n * (p->slab_rank + 1) / p->slab_count);
+  out->row0 = (int)((long long)ny * p->slab_rank / p->slab_count);
+  const int row1 = (int)((long long)ny * (p->slab_rank + 1) / p->slab_count);
   out->rows = row1 - out->row0;
   out->halo_dens = a;
   out->pressure_groups = p->pressure_groups > 1 && p->pressure_iters > 1
@@ -683,7 +685,7 @@ int fluid_slab_plan(const fluid_params *p, fluid_slab_info *out) {
   out->has_lo = p->slab_rank > 0;
   out->has_hi = p->slab_rank < p->slab_count - 1;
   // a halo must come from the adjacent slab alone, and the y-border rules read two rows inward
-  const int min_rows = p->n / p->slab_count;  // the shortest slab
+  const int min_rows = ny / p->slab_count;  // the shortest slab
   if (min_rows < out->halo_vel || min_rows < 4) return FLUID_E_UNSUPPORTED;
   const int lo = out->has_lo ? out->halo_vel : 0, hi = out->has_hi ? out->halo_vel : 0;
   out->store_row0 = out->row0 - lo;
@@ -697,6 +699,7 @@ int fluid_init(fluid_ctx **out, const fluid_params *p) {
   fluid_params prm;
   if (p) prm = *p; else fluid_default_params(&prm);
   if (prm.n < 4 || prm.diffusion_iters < 0 || prm.pressure_iters < 0) return FLUID_E_INVALID;
+  if (prm.ny != 0 && prm.ny < 4) return FLUID_E_INVALID;
   fluid_slab_info si;
   int prc = fluid_slab_plan(&prm, &si);
   if (prc) return prc;
@@ -707,7 +710,7 @@ int fluid_init(fluid_ctx **out, const fluid_params *p) {
   fluid_ctx *c = new (std::nothrow) fluid_ctx();
   if (!c) return FLUID_E_NOMEM;
   c->prm = prm;
-  c->g = Geom{prm.n, si.store_row0, si.store_rows};
+  c->g = Geom{prm.n, si.store_row0, si.store_rows, prm.ny ? prm.ny : prm.n};
   c->row0 = si.row0;
   c->rows = si.rows;
   c->own_r0 = si.row0 - si.store_row0;

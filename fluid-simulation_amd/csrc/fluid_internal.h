@@ -8,9 +8,10 @@
 // stores rows [ybase, ybase + L) (its owned rows plus halo rows); local row r
 // is global row ybase + r.  Whole-domain contexts have ybase = 0, L = n.
 struct Geom {
-  int n;      // global grid edge (cells)
+  int n;      // grid width: columns, and the row pitch of every field (the reference's gridResolution)
   int ybase;  // global y of local row 0
   int L;      // local rows stored
+  int ny;     // grid height: rows of the whole domain (== n for the reference's square grids)
 };
 
 // Kernel ids for per-kernel timing (fluid_profile_steps) and rocprof matching.

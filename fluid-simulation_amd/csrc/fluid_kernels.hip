@@ -70,7 +70,7 @@ struct Rows { int r0, r1; };   // a second row range for the blocks with blockId
 template <typename T>
 __device__ __forceinline__ T texel(const T *t, Geom g, int i, int j, Valid v, int *flag) {
   i = clampi(i, 0, g.n - 1);
-  int r = clampi(j, 0, g.n - 1) - g.ybase;
+  int r = clampi(j, 0, g.ny - 1) - g.ybase;
   if (r < v.lo || r >= v.hi) {
     if (flag) *flag = 1;
     r = clampi(r, 0, g.L - 1);
@@ -95,7 +95,7 @@ __device__ __forceinline__ T bilinear(const T *t, Geom g, Tap p, Valid v, int *f
 // validity test, one address; the same four values, so the same result bit for bit.
 __device__ __forceinline__ bool tap_inside(Tap p, Geom g, Valid v) {
   const int r = p.j - g.ybase;
-  return p.i >= 0 && p.i <= g.n - 2 && p.j >= 0 && p.j <= g.n - 2 && r >= v.lo && r + 1 < v.hi;
+  return p.i >= 0 && p.i <= g.n - 2 && p.j >= 0 && p.j <= g.ny - 2 && r >= v.lo && r + 1 < v.hi;
 }
 typedef float f4a8 __attribute__((ext_vector_type(4), aligned(8)));
 __device__ __forceinline__ float2 bilinear_inside(const float2 *t, Geom g, Tap p) {
@@ -125,7 +125,7 @@ __device__ __forceinline__ float2 linear_at_int(const float2 *t, Geom g, int m, 
   if (x >= g.n || r >= r1) return;                        \
   const int y = g.ybase + r;                              \
   const size_t id = (size_t)r * g.n + x;                  \
-  const bool interior = x > 0 && x < g.n - 1 && y > 0 && y < g.n - 1;
+  const bool interior = x > 0 && x < g.n - 1 && y > 0 && y < g.ny - 1;
 
 // Rows per thread in the two advection kernels.  A backtrace is two dependent memory round
 // trips (own velocity, then the four texels), so a one-cell-per-thread kernel is bound by the
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(BX *BY) void k_advect_vel(Geom g, int r0, int r1, R
     float px = (float)x - dt * v[k].x;
     float py = (float)y - dt * v[k].y;
     px = fmaxf(0.0f, fminf(px, (float)g.n));
-    py = fmaxf(0.0f, fminf(py, (float)g.n));
+    py = fmaxf(0.0f, fminf(py, (float)g.ny));
     tp[k] = tap_of(px, py);
     inside = inside && tap_inside(tp[k], g, valid);
   }
@@ -184,20 +184,20 @@ __global__ __launch_bounds__(BX *BY) void k_advect_vel(Geom g, int r0, int r1, R
 #pragma unroll
     for (int k = 0; k < ADV_ROWS; ++k) {
       const int y = g.ybase + min(rbase + k, r1 - 1);
-      const bool interior = x > 0 && x < g.n - 1 && y > 0 && y < g.n - 1;
+      const bool interior = x > 0 && x < g.n - 1 && y > 0 && y < g.ny - 1;
       o[k] = bilinear(vin, g, tp[k], valid, interior ? flag : nullptr);  // border cells: discarded
     }
   }
 #pragma unroll
   for (int k = 0; k < ADV_ROWS; ++k) {
     const int y = g.ybase + min(rbase + k, r1 - 1);
-    const bool interior = x > 0 && x < g.n - 1 && y > 0 && y < g.n - 1;
+    const bool interior = x > 0 && x < g.n - 1 && y > 0 && y < g.ny - 1;
     if (!interior) {
       float2 b = make_float2(0.0f, 0.0f);
       if (x == 0) b = neg(linear_at_int(vin, g, x + 1, y));
       if (x == g.n - 1) b = neg(linear_at_int(vin, g, x - 1, y));
       if (y == 0) b = neg(linear_at_int(vin, g, x + 1, y + 1));
-      if (y == g.n - 1) b = neg(linear_at_int(vin, g, x + 1, y - 1));
+      if (y == g.ny - 1) b = neg(linear_at_int(vin, g, x + 1, y - 1));
       o[k] = b;
     }
   }
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(BX *BY) void k_advect_dens(Geom g, int r0, int r1, 
     float px = (float)x - dt * v[k].x;
     float py = (float)y - dt * v[k].y;
     px = fmaxf(0.0f, fminf(px, (float)g.n));
-    py = fmaxf(0.0f, fminf(py, (float)g.n));
+    py = fmaxf(0.0f, fminf(py, (float)g.ny));
     tp[k] = tap_of(px, py);
     inside = inside && tap_inside(tp[k], g, valid);
   }
@@ -239,14 +239,14 @@ __global__ __launch_bounds__(BX *BY) void k_advect_dens(Geom g, int r0, int r1, 
 #pragma unroll
     for (int k = 0; k < ADV_ROWS; ++k) {
       const int y = g.ybase + min(rbase + k, r1 - 1);
-      const bool interior = x > 0 && x < g.n - 1 && y > 0 && y < g.n - 1;
+      const bool interior = x > 0 && x < g.n - 1 && y > 0 && y < g.ny - 1;
       o[k] = bilinear(din, g, tp[k], valid, interior ? flag : nullptr);
     }
   }
 #pragma unroll
   for (int k = 0; k < ADV_ROWS; ++k) {
     const int y = g.ybase + min(rbase + k, r1 - 1);
-    if (!(x > 0 && x < g.n - 1 && y > 0 && y < g.n - 1)) o[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (!(x > 0 && x < g.n - 1 && y > 0 && y < g.ny - 1)) o[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   }
 #pragma unroll
   for (int k = 0; k < ADV_ROWS; ++k)
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(BX *BY) void k_jacobi(Geom g, int r0, int r1,
     if (x == 0) o = -pin[id + 1];
     if (x == g.n - 1) o = -pin[id - 1];
     if (y == 0) o = -pin[id + g.n];
-    if (y == g.n - 1) o = -pin[id - g.n];
+    if (y == g.ny - 1) o = -pin[id - g.n];
     pout[id] = o;
   }
 }
@@ -317,7 +317,7 @@ __device__ __forceinline__ float2 project_cell(Geom g, int x, int y, int r, size
   if (x == 0) o = neg(vin[id + 1]);
   if (x == g.n - 1) o = neg(vin[id - 1]);
   if (y == 0) o = neg(vin[(size_t)(r + 1) * g.n + xp]);
-  if (y == g.n - 1) o = neg(vin[(size_t)(r - 1) * g.n + xp]);
+  if (y == g.ny - 1) o = neg(vin[(size_t)(r - 1) * g.n + xp]);
   return o;
 }
 __global__ __launch_bounds__(BX *BY) void k_project(Geom g, int r0, int r1,
@@ -346,13 +346,13 @@ __global__ __launch_bounds__(BX *TAIL_BY) void k_project_advect_dens(
   if (x >= g.n || r >= r1) return;
   const int y = g.ybase + r;
   const size_t id = (size_t)r * g.n + x;
-  const bool interior = x > 0 && x < g.n - 1 && y > 0 && y < g.n - 1;
+  const bool interior = x > 0 && x < g.n - 1 && y > 0 && y < g.ny - 1;
   const float2 v = project_cell(g, x, y, r, id, interior, vin, p);
   store_out<NT>(vout + id, v);
   float px = (float)x - dt * v.x;
   float py = (float)y - dt * v.y;
   px = fmaxf(0.0f, fminf(px, (float)g.n));
-  py = fmaxf(0.0f, fminf(py, (float)g.n));
+  py = fmaxf(0.0f, fminf(py, (float)g.ny));
   const Tap tp = tap_of(px, py);
   float4 o;
   if (__all(tap_inside(tp, g, valid))) o = bilinear_inside(din, g, tp);
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(BX *BY) void k_add_force(Geom g, int r0, int r1, fl
   CELL_PROLOGUE
   (void)interior;
   float dx = ((float)x / (float)g.n) - sx;
-  float dy = ((float)y / (float)g.n) - sy;
+  float dy = ((float)y / (float)g.ny) - sy;
   float c = expf(-(dx * dx + dy * dy) / radius) * dt;
   float2 v = vel[id];
   vel[id] = make_float2(v.x + c * fx, v.y + c * fy);

@@ -64,7 +64,7 @@ __global__ __launch_bounds__(DIAG_THREADS) void k_diagnostics(Geom g, int r0, in
   for (int k = 0; k < DIAG_NSUM; ++k) sm[k] = 0.0f;
   for (int r = r0 + (int)blockIdx.x; r < r1; r += (int)gridDim.x) {
     const int y = g.ybase + r;
-    const bool yin = y >= 1 && y <= g.n - 2;
+    const bool yin = y >= 1 && y <= g.ny - 2;
     for (int x = (int)threadIdx.x; x < g.n; x += DIAG_THREADS) {
       const size_t id = (size_t)r * g.n + x;
       const float2 u = vel[id];

@@ -253,9 +253,9 @@ template <int C> struct JacobiOp {
 
   template <bool XEDGE, bool YCHK>
   static __device__ __forceinline__ R apply(const R &a, const R &b, const R &n, const A &d, int r,
-                                            int x0, int N, const P &, XBorder xb) {
+                                            int x0, int N, int NY, const P &, XBorder xb) {
     R o;
-    if (YCHK && (r <= 0 || r >= N - 1)) {  // wave-uniform
+    if (YCHK && (r <= 0 || r >= NY - 1)) {  // wave-uniform
 #pragma unroll
       for (int c = 0; c < C; ++c) {  // y == 0: -p[x,1]; y == N-1: -p[x,N-2]  (kernel.cu:321-322)
         const float nv = n.v[c], av = a.v[c];  // values, not a select of addresses (keeps SROA)
@@ -319,8 +319,8 @@ template <int C> struct DiffuseOp {
 
   template <bool XEDGE, bool YCHK>
   static __device__ __forceinline__ R apply(const R &a, const R &b, const R &n, const A &, int r,
-                                            int x0, int N, const P &p, XBorder xb) {
-    if (YCHK && (r <= 0 || r >= N - 1)) return b;  // border copies through, kernel.cu:201-203
+                                            int x0, int N, int NY, const P &p, XBorder xb) {
+    if (YCHK && (r <= 0 || r >= NY - 1)) return b;  // border copies through, kernel.cu:201-203
     R o;
     const float alpha = p.alpha, beta = p.beta;
     if constexpr (TB_ASM && C == 2) {
@@ -382,8 +382,8 @@ template <int C> struct JacobiDivOp : JacobiOp<C> {
 
   template <bool XEDGE, bool YCHK>
   static __device__ __forceinline__ R apply(const R &a, const R &b, const R &n, const A &d, int r,
-                                            int x0, int N, const P &, XBorder xb) {
-    return JacobiOp<C>::template apply<XEDGE, YCHK>(a, b, n, d, r, x0, N, typename JacobiOp<C>::P{}, xb);
+                                            int x0, int N, int NY, const P &, XBorder xb) {
+    return JacobiOp<C>::template apply<XEDGE, YCHK>(a, b, n, d, r, x0, N, NY, typename JacobiOp<C>::P{}, xb);
   }
 
   template <bool XEDGE> struct Feed {
@@ -409,7 +409,7 @@ template <int C> struct JacobiDivOp : JacobiOp<C> {
       vpf[J % RING] = load_row2<C>(p.vel + voff);       // refill the freed slot
       A d;
       const int N = pp.g.n;
-      if (YCHK && (t <= 0 || t >= N - 1)) {  // wave-uniform: border rows, kernel.cu:287
+      if (YCHK && (t <= 0 || t >= pp.g.ny - 1)) {  // wave-uniform: border rows, kernel.cu:287
         d = zero_row<C>();
       } else {
         const float lu = from_left(vb.u[C - 1]);
@@ -510,7 +510,7 @@ template <class Op, int K, bool XEDGE> struct Pipe {
       A d = cur;  // a copy of the value (never a select between two rows' addresses)
       if (l > 0) d = hh(l + 1 - J % 3);
       R o = Op::template apply<XEDGE, YCHK>(s[l][J % 3], s[l][(J + 1) % 3], s[l][(J + 2) % 3], d,
-                                            t - l - 1, x0, g.n, p, xb);
+                                            t - l - 1, x0, g.n, g.ny, p, xb);
       if (l + 1 < K) s[l + 1][(J + 2) % 3] = o; else fin = o;
     }
     return fin;
@@ -532,7 +532,7 @@ template <class Op, int K, bool XEDGE> struct Pipe {
                                      areal ? p.div_out + off(t) : p.dump + (size_t)g.n + xc);
     }
     R fin;
-    if (t - K >= 1 && t - 1 <= g.n - 2) fin = levels<J, false>(p, t, cur);  // every level's row is y-interior
+    if (t - K >= 1 && t - 1 <= g.ny - 2) fin = levels<J, false>(p, t, cur);  // every level's row is y-interior
     else fin = levels<J, true>(p, t, cur);
     const int ro = t - K;  // level K row just produced
     Op::store_at(Op::out_ptr(p, st_ok && ro >= ya && ro < yb, off(ro), (size_t)xc), fin);
@@ -579,7 +579,7 @@ template <class Op, int K, bool XEDGE> struct Pipe {
     static_assert(RING == 3 || RING == 6, "the time loop is unrolled by a multiple of the slot period");
     // steady window [lo, hi] of steps, then the groups of three that lie inside it
     const int lo = max(ya + K, K + 1);
-    const int hi = min(min((Op::kStoresAux ? yb : yb + K) - 1, g.n - 1), g.ybase + g.L - 2 - RING);
+    const int hi = min(min((Op::kStoresAux ? yb : yb + K) - 1, g.ny - 1), g.ybase + g.L - 2 - RING);
     const int tsa = t0 + RING * ((lo - t0 + RING - 1) / RING);
     const int tea = hi - (RING - 1) >= tsa ? t0 + RING * ((hi - (RING - 1) - t0) / RING) : tsa - RING;
     Steady st;

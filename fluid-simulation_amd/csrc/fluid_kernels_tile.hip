@@ -49,12 +49,12 @@ struct JacobiRule {
   static __device__ __forceinline__ float interior(float L, float Rt, float B, float T, float, float d, float, float) {
     return ((((L + Rt) + B) + T) + (-1.0f) * d) * 0.25f;
   }
-  static __device__ __forceinline__ float border(float L, float Rt, float B, float T, float, int x, int y, int n) {
+  static __device__ __forceinline__ float border(float L, float Rt, float B, float T, float, int x, int y, int n, int ny) {
     float o = 0.0f;
     if (x == 0) o = -Rt;
     if (x == n - 1) o = -L;
     if (y == 0) o = -T;
-    if (y == n - 1) o = -B;
+    if (y == ny - 1) o = -B;
     return o;
   }
   // the same rules one side at a time (border tiles: the side is known per run, see Run)
@@ -68,7 +68,7 @@ struct DiffuseRule {
   static __device__ __forceinline__ float interior(float L, float Rt, float B, float T, float c, float, float alpha, float beta) {
     return ((((L + Rt) + B) + T) + alpha * c) * beta;
   }
-  static __device__ __forceinline__ float border(float, float, float, float, float c, int, int, int) { return c; }
+  static __device__ __forceinline__ float border(float, float, float, float, float c, int, int, int, int) { return c; }
   static __device__ __forceinline__ float x0(float, float, float c) { return c; }
   static __device__ __forceinline__ float x1(float, float, float c) { return c; }
   static __device__ __forceinline__ float y0(float, float, float c) { return c; }
@@ -92,7 +92,7 @@ template <int K> struct Run {
   // TILE_BORDER: the run's segment holds column 0 / column n-1 (its first / last cell: n % 4 == 0);
   // row j of the run is row 0 / row n-1; the segment lies inside the domain in x
   bool bx0, bx1, by0[R], by1[R], yb, in_x;
-  __device__ __forceinline__ void locate(int x_org, int y_org, int n) {
+  __device__ __forceinline__ void locate(int x_org, int y_org, int n, int ny) {
     using G = TileGeom<K>;
     const int run = threadIdx.x;
     const int rr = run / G::W4, sx = run - rr * G::W4, ly0 = rr * R;
@@ -111,7 +111,7 @@ template <int K> struct Run {
 #pragma unroll
     for (int j = 0; j < R; ++j) {
       by0[j] = y + j == 0;
-      by1[j] = y + j == n - 1;
+      by1[j] = y + j == ny - 1;
       yb = yb || by0[j] || by1[j];
     }
   }
@@ -122,7 +122,7 @@ template <int K> struct Run {
 // go to LDS (b) for the neighbours.
 template <int K, class Rule>
 __device__ __forceinline__ void run_sweep(const float *__restrict__ a, float *__restrict__ b, const Run<K> &rn,
-                                          F4 (&ce)[R], const F4 (&aux)[R], int mode, int n, float alpha,
+                                          F4 (&ce)[R], const F4 (&aux)[R], int mode, int n, int ny, float alpha,
                                           float beta) {
   using G = TileGeom<K>;
   const F4 rm = ld4(a + rn.cm), rp = ld4(a + rn.cp);
@@ -142,8 +142,8 @@ __device__ __forceinline__ void run_sweep(const float *__restrict__ a, float *__
       float v = Rule::interior(L, Rt, up.v[i], dn.v[i], ce[j].v[i], aux[j].v[i], alpha, beta);
       if (mode == TILE_CELLS) {
         const int x = rn.x + i, y = rn.y + j;
-        if (x <= 0 || x >= n - 1 || y <= 0 || y >= n - 1)
-          v = Rule::border(L, Rt, up.v[i], dn.v[i], ce[j].v[i], x, y, n);
+        if (x <= 0 || x >= n - 1 || y <= 0 || y >= ny - 1)
+          v = Rule::border(L, Rt, up.v[i], dn.v[i], ce[j].v[i], x, y, n, ny);
       }
       o[j].v[i] = v;
     }
@@ -214,11 +214,11 @@ __global__ __launch_bounds__(TileGeom<K>::THREADS) void k_jacobi_tile(Geom g, in
   // row inside the stored rows to take the unclamped path (a slab's tile can start at its local
   // row 0 without touching the domain border)
   constexpr int RM = WITH_DIV ? 1 : 0;
-  const bool edge = x_org <= 0 || x_org + G::W >= n || y_org <= 0 || y_org + G::H >= n || r_org < RM ||
+  const bool edge = x_org <= 0 || x_org + G::W >= n || y_org <= 0 || y_org + G::H >= g.ny || r_org < RM ||
                     r_org + G::H > g.L - RM;
   const int mode = (n & 3) ? TILE_CELLS : edge ? TILE_BORDER : TILE_INSIDE;
   Run<K> rn;
-  rn.locate(x_org, y_org, n);
+  rn.locate(x_org, y_org, n, g.ny);
   F4 ce[R], dv[R];
   const F4 zero = F4{{0.0f, 0.0f, 0.0f, 0.0f}};
 #pragma unroll
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(TileGeom<K>::THREADS) void k_jacobi_tile(Geom g, in
       for (int i = 0; i < 4; ++i) {
         const int x = clampi(rn.x + i, 0, n - 1), r = rc, y = g.ybase + r;
         float d = 0.0f;
-        if (x > 0 && x < n - 1 && y > 0 && y < n - 1) {
+        if (x > 0 && x < n - 1 && y > 0 && y < g.ny - 1) {
           const size_t id = (size_t)r * n + x;
           const size_t up = (size_t)min(r + 1, g.L - 1) * n + x, dn = (size_t)max(r - 1, 0) * n + x;
           const float2 vL = vel[id - 1], vR = vel[id + 1], vB = vel[dn], vT = vel[up];
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(TileGeom<K>::THREADS) void k_jacobi_tile(Geom g, in
   __syncthreads();
 #pragma unroll 1
   for (int s = 0; s < K; ++s) {
-    if (rn.active) run_sweep<K, JacobiRule>(a, b, rn, ce, dv, mode, n, 0.0f, 0.0f);
+    if (rn.active) run_sweep<K, JacobiRule>(a, b, rn, ce, dv, mode, n, g.ny, 0.0f, 0.0f);
     __syncthreads();
     float *t = a; a = b; b = t;
   }
@@ -323,11 +323,11 @@ __global__ __launch_bounds__(TileGeom<K>::THREADS) void k_diffuse_tile(Geom g, i
   const int x_org = blockIdx.x * TX - G::HX;
   const int r_org = r0 + blockIdx.y * TY - K;
   const int y_org = g.ybase + r_org;
-  const bool edge = x_org <= 0 || x_org + G::W >= n || y_org <= 0 || y_org + G::H >= n || r_org < 0 ||
+  const bool edge = x_org <= 0 || x_org + G::W >= n || y_org <= 0 || y_org + G::H >= g.ny || r_org < 0 ||
                     r_org + G::H > g.L;
   const int mode = (n & 3) ? TILE_CELLS : edge ? TILE_BORDER : TILE_INSIDE;
   Run<K> rn;
-  rn.locate(x_org, y_org, n);
+  rn.locate(x_org, y_org, n, g.ny);
   F4 cu[R], cw[R], none[R];
 #pragma unroll
   for (int j = 0; j < R; ++j) {
@@ -358,8 +358,8 @@ __global__ __launch_bounds__(TileGeom<K>::THREADS) void k_diffuse_tile(Geom g, i
 #pragma unroll 1
   for (int s = 0; s < K; ++s) {
     if (rn.active) {
-      run_sweep<K, DiffuseRule>(au, bu, rn, cu, none, mode, n, alpha, beta);
-      run_sweep<K, DiffuseRule>(aw, bw, rn, cw, none, mode, n, alpha, beta);
+      run_sweep<K, DiffuseRule>(au, bu, rn, cu, none, mode, n, g.ny, alpha, beta);
+      run_sweep<K, DiffuseRule>(aw, bw, rn, cw, none, mode, n, g.ny, alpha, beta);
     }
     __syncthreads();
     float *t = au; au = bu; bu = t;

@@ -7,7 +7,7 @@
  * instead of mouseMove (:870-878), fluid_read and an image file instead of
  * glDrawPixels (:753-755).  Pure C; links libfluid_hip.so.
  *
- *   fluid_headless [--n N] [--diffusion D] [--jacobi J] [--steps S] [--warmup W]
+ *   fluid_headless [--n N] [--ny ROWS] [--diffusion D] [--jacobi J] [--steps S] [--warmup W]
  *                  [--windows K] [--unfused] [--no-graph] [--vorticity] [--device I]
  *                  [--dump PREFIX] [--splats]
  *       timed run on the seeded splat script; prints one JSON line
@@ -248,15 +248,15 @@ static int replay(fluid_ctx *ctx, const event_t *ev, int nev, int frames, int wi
 /* ---- visualizationStep() without the window (kernel.cu:389-431, :710-756) -------------------- */
 static float clamp01(float v) { return v < 0.f ? 0.f : v > 1.f ? 1.f : v; }
 
-static int write_view(fluid_ctx *ctx, int n, int view, int width, int height, const char *ppm, const char *pfm) {
+static int write_view(fluid_ctx *ctx, int n, int rows, int view, int width, int height, const char *ppm, const char *pfm) {
   static const int field_of[3] = {FLUID_DENSITY, FLUID_VELOCITY, FLUID_PRESSURE};
   static const int comps_of[3] = {4, 2, 1};
   const int comps = comps_of[view];
-  float *fld = (float *)malloc(sizeof(float) * comps * (size_t)n * n);
+  float *fld = (float *)malloc(sizeof(float) * comps * (size_t)n * rows);
   float *img = (float *)calloc(4 * (size_t)width * height, sizeof(float));
   if (!fld || !img) { free(fld); free(img); return 1; }
-  CHECK(fluid_read(ctx, field_of[view], fld, sizeof(float) * comps * (size_t)n * n));
-  for (int y = 0; y < height && y < n; ++y)       /* threads exist for id < n only, kernel.cu:439-440 */
+  CHECK(fluid_read(ctx, field_of[view], fld, sizeof(float) * comps * (size_t)n * rows));
+  for (int y = 0; y < height && y < rows; ++y)    /* threads exist for id < n only, kernel.cu:439-440 */
     for (int x = 0; x < width && x < n; ++x) {
       const size_t t = (size_t)y * n + x;         /* tex2D(tex, id.x, id.y), point filter: texel (x, y) */
       float *o = img + 4 * ((size_t)y * width + x); /* visualizationBuffer[id.x + id.y * width] */
@@ -334,6 +334,7 @@ int main(int argc, char **argv) {
   const char *dump = NULL, *replay_path = NULL, *ppm = NULL, *pfm = NULL, *comm_file = NULL;
   for (int i = 1; i < argc; ++i) {
     if (!strcmp(argv[i], "--n") && i + 1 < argc) prm.n = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--ny") && i + 1 < argc) prm.ny = atoi(argv[++i]); /* rows; default = n (square) */
     else if (!strcmp(argv[i], "--diffusion") && i + 1 < argc) prm.diffusion_iters = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--jacobi") && i + 1 < argc) prm.pressure_iters = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--steps") && i + 1 < argc) steps = atoi(argv[++i]);
@@ -374,7 +375,7 @@ int main(int argc, char **argv) {
   prm.device = device >= 0 ? device : (slabs ? prm.slab_rank : 0);
   if (windows < 1) windows = 1;
   if (windows > 64) windows = 64;
-  if (win_w <= 0 || win_h <= 0) win_w = win_h = prm.n; /* the reference's window is the grid, kernel.cu:438, :466-467 */
+  if (win_w <= 0 || win_h <= 0) { win_w = prm.n; win_h = prm.ny ? prm.ny : prm.n; } /* the reference's window is the grid, kernel.cu:438, :466-467 */
   CHECK(fluid_init(&ctx, &prm));
   int n = 0, row0 = 0, rows = 0;
   CHECK(fluid_geometry(ctx, &n, &row0, &rows));
@@ -420,7 +421,7 @@ int main(int argc, char **argv) {
     }
     qsort(ms, windows, sizeof(float), cmp_float);
     double t_step = ms[windows / 2] / (steps > 0 ? steps : 1) * 1e-3;
-    double cells = (double)prm.n * prm.n;
+    double cells = (double)prm.n * (prm.ny ? prm.ny : prm.n);
     double bpc = 88.0 + 16.0 * prm.diffusion_iters + 12.0 * prm.pressure_iters;
     fluid_diag dg; /* state after the timed steps: wavefront reductions on the device (own rows) */
     if (slabs) CHECK(fluid_comm_refresh(ctx));
@@ -441,7 +442,7 @@ int main(int argc, char **argv) {
   }
 
   if (ppm || pfm) {
-    if (write_view(ctx, n, view < 0 ? 0 : view, win_w, win_h, ppm, pfm)) { fprintf(stderr, "writing the frame failed\n"); return 1; }
+    if (write_view(ctx, n, rows, view < 0 ? 0 : view, win_w, win_h, ppm, pfm)) { fprintf(stderr, "writing the frame failed\n"); return 1; }
   }
   if (dump) {
     char prefix[600];

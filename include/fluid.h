@@ -90,7 +90,12 @@ typedef struct fluid_params {
   int halo_rows;       /* A: advection reach in rows when slab-decomposed (0 = 8) */
   int pressure_groups; /* slab contexts: split the J sweeps into this many groups with a
                           pressure-halo exchange between them (0/1 = one group); see below */
-  int reserved[4];     /* must be zero                                        */
+  int ny;              /* rows of the grid; 0 = n (square, the reference's only case:
+                          kernel.cu:438).  n is then the number of columns: index = x + y*n,
+                          x < n, y < ny.  Every rule keeps its form with the extent taken per
+                          axis (x tests and clamps against n, y tests and clamps against ny;
+                          fluid_add_source normalises x by n and y by ny)                 */
+  int reserved[3];     /* must be zero                                        */
 } fluid_params;
 
 typedef struct fluid_ctx fluid_ctx;
@@ -196,7 +201,8 @@ typedef struct fluid_diag {
 } fluid_diag;
 FLUID_API int fluid_diagnostics(fluid_ctx *ctx, fluid_diag *out);
 
-/* Geometry of this context: grid edge, first owned row, number of owned rows. */
+/* Geometry of this context: grid width (columns), first owned row, number of owned rows (for a
+ * whole-domain context: 0 and the grid height ny). */
 FLUID_API int fluid_geometry(const fluid_ctx *ctx, int *n, int *row0, int *rows);
 
 /* Human-readable text for a FLUID_E_* code; never NULL. */

@@ -68,45 +68,45 @@ static inline f4 mix4(f4 x, f4 y, float a) {
 static inline f2 neg2(f2 v) { f2 r = { -v.x, -v.y }; return r; }
 
 /* POINT fetch, clamp-to-edge (Appendix B.1). */
-static inline f2 texel2(const f2 *t, int n, int i, int j) {
-  return t[clampi(i, 0, n - 1) + (size_t)clampi(j, 0, n - 1) * n];
+static inline f2 texel2(const f2 *t, int nx, int ny, int i, int j) {
+  return t[clampi(i, 0, nx - 1) + (size_t)clampi(j, 0, ny - 1) * nx];
 }
-static inline f4 texel4(const f4 *t, int n, int i, int j) {
-  return t[clampi(i, 0, n - 1) + (size_t)clampi(j, 0, n - 1) * n];
+static inline f4 texel4(const f4 *t, int nx, int ny, int i, int j) {
+  return t[clampi(i, 0, nx - 1) + (size_t)clampi(j, 0, ny - 1) * nx];
 }
-static inline float texel1(const float *t, int n, int i, int j) {
-  return t[clampi(i, 0, n - 1) + (size_t)clampi(j, 0, n - 1) * n];
+static inline float texel1(const float *t, int nx, int ny, int i, int j) {
+  return t[clampi(i, 0, nx - 1) + (size_t)clampi(j, 0, ny - 1) * nx];
 }
 
 /* LINEAR fetch at texture coordinate (bx + 0.5, by + 0.5), i.e. bilinear with
  * base texel floor(bx), weight frac(bx) computed from bx directly (Appendix
  * B.2: do not round-trip through +0.5-0.5). */
-static inline f2 bilinear2(const f2 *t, int n, float bx, float by) {
+static inline f2 bilinear2(const f2 *t, int nx, int ny, float bx, float by) {
   float fi = floorf(bx), fj = floorf(by);
   float a = bx - fi, b = by - fj;
   int i = (int)fi, j = (int)fj;
-  f2 v0 = mix2(texel2(t, n, i, j), texel2(t, n, i + 1, j), a);
-  f2 v1 = mix2(texel2(t, n, i, j + 1), texel2(t, n, i + 1, j + 1), a);
+  f2 v0 = mix2(texel2(t, nx, ny, i, j), texel2(t, nx, ny, i + 1, j), a);
+  f2 v1 = mix2(texel2(t, nx, ny, i, j + 1), texel2(t, nx, ny, i + 1, j + 1), a);
   return mix2(v0, v1, b);
 }
-static inline f4 bilinear4(const f4 *t, int n, float bx, float by) {
+static inline f4 bilinear4(const f4 *t, int nx, int ny, float bx, float by) {
   float fi = floorf(bx), fj = floorf(by);
   float a = bx - fi, b = by - fj;
   int i = (int)fi, j = (int)fj;
-  f4 v0 = mix4(texel4(t, n, i, j), texel4(t, n, i + 1, j), a);
-  f4 v1 = mix4(texel4(t, n, i, j + 1), texel4(t, n, i + 1, j + 1), a);
+  f4 v0 = mix4(texel4(t, nx, ny, i, j), texel4(t, nx, ny, i + 1, j), a);
+  f4 v1 = mix4(texel4(t, nx, ny, i, j + 1), texel4(t, nx, ny, i + 1, j + 1), a);
   return mix4(v0, v1, b);
 }
 /* LINEAR fetch at INTEGER texture coordinates (m, n) (Appendix B.3): base
  * texel (m-1, n-1), both weights exactly 0.5 => 2x2 mean in mix() form. */
-static inline f2 linear_at_int2(const f2 *t, int n, int m, int k) {
-  f2 v0 = mix2(texel2(t, n, m - 1, k - 1), texel2(t, n, m, k - 1), 0.5f);
-  f2 v1 = mix2(texel2(t, n, m - 1, k), texel2(t, n, m, k), 0.5f);
+static inline f2 linear_at_int2(const f2 *t, int nx, int ny, int m, int k) {
+  f2 v0 = mix2(texel2(t, nx, ny, m - 1, k - 1), texel2(t, nx, ny, m, k - 1), 0.5f);
+  f2 v1 = mix2(texel2(t, nx, ny, m - 1, k), texel2(t, nx, ny, m, k), 0.5f);
   return mix2(v0, v1, 0.5f);
 }
 
-static inline int interior(int x, int y, int n) {
-  return x > 0 && x < n - 1 && y > 0 && y < n - 1;
+static inline int interior(int x, int y, int nx, int ny) {
+  return x > 0 && x < nx - 1 && y > 0 && y < ny - 1;
 }
 
 /* ------------------------------------------------------------------------- */
@@ -114,48 +114,48 @@ static inline int interior(int x, int y, int n) {
 /* ------------------------------------------------------------------------- */
 
 /* kernel.cu:114-140 */
-void ref_advection(int n, float dt, const float *vel_in, float *vel_out) {
+void ref_advection_rect(int nx, int ny, float dt, const float *vel_in, float *vel_out) {
   const f2 *vin = (const f2 *)vel_in;
   f2 *vout = (f2 *)vel_out;
   OMP_ROWS
-  for (int y = 0; y < n; ++y)
-    for (int x = 0; x < n; ++x) {
-      size_t id = x + (size_t)y * n;
-      if (interior(x, y, n)) {
+  for (int y = 0; y < ny; ++y)
+    for (int x = 0; x < nx; ++x) {
+      size_t id = x + (size_t)y * nx;
+      if (interior(x, y, nx, ny)) {
         f2 v = vin[id]; /* :125 LINEAR at texel centre = exact texel */
         float px = (float)x - dt * v.x; /* :126 */
         float py = (float)y - dt * v.y;
-        px = clampf(px, 0.0f, (float)n); /* :130 */
-        py = clampf(py, 0.0f, (float)n);
-        vout[id] = bilinear2(vin, n, px, py); /* :131 */
+        px = clampf(px, 0.0f, (float)nx); /* :130 */
+        py = clampf(py, 0.0f, (float)ny);
+        vout[id] = bilinear2(vin, nx, ny, px, py); /* :131 */
       } else {
         f2 o = { 0.0f, 0.0f }; /* unreachable default: one of the ifs is always true */
-        if (x == 0) o = neg2(linear_at_int2(vin, n, x + 1, y));         /* :135 */
-        if (x == n - 1) o = neg2(linear_at_int2(vin, n, x - 1, y));     /* :136 */
-        if (y == 0) o = neg2(linear_at_int2(vin, n, x + 1, y + 1));     /* :137 */
-        if (y == n - 1) o = neg2(linear_at_int2(vin, n, x + 1, y - 1)); /* :138 */
+        if (x == 0) o = neg2(linear_at_int2(vin, nx, ny, x + 1, y));         /* :135 */
+        if (x == nx - 1) o = neg2(linear_at_int2(vin, nx, ny, x - 1, y));     /* :136 */
+        if (y == 0) o = neg2(linear_at_int2(vin, nx, ny, x + 1, y + 1));     /* :137 */
+        if (y == ny - 1) o = neg2(linear_at_int2(vin, nx, ny, x + 1, y - 1)); /* :138 */
         vout[id] = o;
       }
     }
 }
 
 /* kernel.cu:142-165 */
-void ref_advection_density(int n, float dt, const float *vel, const float *dens_in,
+void ref_advection_density_rect(int nx, int ny, float dt, const float *vel, const float *dens_in,
                            float *dens_out) {
   const f2 *v2 = (const f2 *)vel;
   const f4 *din = (const f4 *)dens_in;
   f4 *dout = (f4 *)dens_out;
   OMP_ROWS
-  for (int y = 0; y < n; ++y)
-    for (int x = 0; x < n; ++x) {
-      size_t id = x + (size_t)y * n;
-      if (interior(x, y, n)) {
+  for (int y = 0; y < ny; ++y)
+    for (int x = 0; x < nx; ++x) {
+      size_t id = x + (size_t)y * nx;
+      if (interior(x, y, nx, ny)) {
         f2 v = v2[id]; /* :154 POINT */
         float px = (float)x - dt * v.x; /* :156 */
         float py = (float)y - dt * v.y;
-        px = clampf(px, 0.0f, (float)n); /* :158 */
-        py = clampf(py, 0.0f, (float)n);
-        dout[id] = bilinear4(din, n, px, py); /* :159 */
+        px = clampf(px, 0.0f, (float)nx); /* :158 */
+        py = clampf(py, 0.0f, (float)ny);
+        dout[id] = bilinear4(din, nx, ny, px, py); /* :159 */
       } else {
         f4 z = { 0.0f, 0.0f, 0.0f, 0.0f }; /* :163 */
         dout[id] = z;
@@ -164,17 +164,17 @@ void ref_advection_density(int n, float dt, const float *vel, const float *dens_
 }
 
 /* kernel.cu:173-205 */
-void ref_diffusion(int n, float dt, float viscosity, const float *vel_in, float *vel_out) {
+void ref_diffusion_rect(int nx, int ny, float dt, float viscosity, const float *vel_in, float *vel_out) {
   const f2 *vin = (const f2 *)vel_in;
   f2 *vout = (f2 *)vel_out;
   float alpha = 1.0f / (viscosity * dt); /* :182 */
   float beta = 1.0f / (4.0f + alpha);    /* :183 */
   OMP_ROWS
-  for (int y = 0; y < n; ++y)
-    for (int x = 0; x < n; ++x) {
-      size_t id = x + (size_t)y * n;
-      if (interior(x, y, n)) {
-        f2 vL = vin[id - 1], vR = vin[id + 1], vB = vin[id - n], vT = vin[id + n];
+  for (int y = 0; y < ny; ++y)
+    for (int x = 0; x < nx; ++x) {
+      size_t id = x + (size_t)y * nx;
+      if (interior(x, y, nx, ny)) {
+        f2 vL = vin[id - 1], vR = vin[id + 1], vB = vin[id - nx], vT = vin[id + nx];
         f2 v = vin[id];
         f2 o; /* :195  (vL + vR + vB + vT + alpha * velocity) * beta */
         o.x = ((((vL.x + vR.x) + vB.x) + vT.x) + alpha * v.x) * beta;
@@ -187,14 +187,14 @@ void ref_diffusion(int n, float dt, float viscosity, const float *vel_in, float 
 }
 
 /* kernel.cu:207-230 */
-void ref_vorticity(int n, const float *vel, float *vort) {
+void ref_vorticity_rect(int nx, int ny, const float *vel, float *vort) {
   const f2 *v = (const f2 *)vel;
   OMP_ROWS
-  for (int y = 0; y < n; ++y)
-    for (int x = 0; x < n; ++x) {
-      size_t id = x + (size_t)y * n;
-      if (interior(x, y, n)) {
-        f2 vL = v[id - 1], vR = v[id + 1], vB = v[id - n], vT = v[id + n];
+  for (int y = 0; y < ny; ++y)
+    for (int x = 0; x < nx; ++x) {
+      size_t id = x + (size_t)y * nx;
+      if (interior(x, y, nx, ny)) {
+        f2 vL = v[id - 1], vR = v[id + 1], vB = v[id - nx], vT = v[id + nx];
         vort[id] = (vR.y - vL.y) - (vT.x - vB.x); /* :222 */
       } else {
         vort[id] = 0.0f; /* :228 */
@@ -203,15 +203,15 @@ void ref_vorticity(int n, const float *vel, float *vort) {
 }
 
 /* kernel.cu:232-263 */
-void ref_add_vorticity(int n, float dt, const float *vort, float *vel) {
+void ref_add_vorticity_rect(int nx, int ny, float dt, const float *vort, float *vel) {
   f2 *v = (f2 *)vel;
   const float scale = 0.2f; /* :239 */
   OMP_ROWS
-  for (int y = 0; y < n; ++y)
-    for (int x = 0; x < n; ++x) {
-      size_t id = x + (size_t)y * n;
-      if (!interior(x, y, n)) continue;
-      float vL = vort[id - 1], vR = vort[id + 1], vB = vort[id - n], vT = vort[id + n];
+  for (int y = 0; y < ny; ++y)
+    for (int x = 0; x < nx; ++x) {
+      size_t id = x + (size_t)y * nx;
+      if (!interior(x, y, nx, ny)) continue;
+      float vL = vort[id - 1], vR = vort[id + 1], vB = vort[id - nx], vT = vort[id + nx];
       float gx = vR - vL, gy = vT - vB; /* :249 gradV = (gx, gy, 0, 0) */
       /* :252 dot(float4,float4) = x*x + y*y + z*z + w*w, left to right */
       float d = ((gx * gx + gy * gy) + 0.0f * 0.0f) + 0.0f * 0.0f;
@@ -228,14 +228,14 @@ void ref_add_vorticity(int n, float dt, const float *vort, float *vel) {
 }
 
 /* kernel.cu:265-289 */
-void ref_divergence(int n, const float *vel, float *div) {
+void ref_divergence_rect(int nx, int ny, const float *vel, float *div) {
   const f2 *v = (const f2 *)vel;
   OMP_ROWS
-  for (int y = 0; y < n; ++y)
-    for (int x = 0; x < n; ++x) {
-      size_t id = x + (size_t)y * n;
-      if (interior(x, y, n)) {
-        f2 vL = v[id - 1], vR = v[id + 1], vB = v[id - n], vT = v[id + n];
+  for (int y = 0; y < ny; ++y)
+    for (int x = 0; x < nx; ++x) {
+      size_t id = x + (size_t)y * nx;
+      if (interior(x, y, nx, ny)) {
+        f2 vL = v[id - 1], vR = v[id + 1], vB = v[id - nx], vT = v[id + nx];
         div[id] = 0.5f * ((vR.x - vL.x) + (vT.y - vB.y)); /* :282 */
       } else {
         div[id] = 0.0f; /* :287 */
@@ -244,62 +244,62 @@ void ref_divergence(int n, const float *vel, float *div) {
 }
 
 /* kernel.cu:291-324 */
-void ref_pressure_jacobi(int n, const float *p_in, const float *div, float *p_out) {
+void ref_pressure_jacobi_rect(int nx, int ny, const float *p_in, const float *div, float *p_out) {
   OMP_ROWS
-  for (int y = 0; y < n; ++y)
-    for (int x = 0; x < n; ++x) {
-      size_t id = x + (size_t)y * n;
-      if (interior(x, y, n)) {
+  for (int y = 0; y < ny; ++y)
+    for (int x = 0; x < nx; ++x) {
+      size_t id = x + (size_t)y * nx;
+      if (interior(x, y, nx, ny)) {
         float alpha = -1.0f, beta = 0.25f; /* :303-304 */
-        float vL = p_in[id - 1], vR = p_in[id + 1], vB = p_in[id - n], vT = p_in[id + n];
+        float vL = p_in[id - 1], vR = p_in[id + 1], vB = p_in[id - nx], vT = p_in[id + nx];
         float d = div[id];
         p_out[id] = ((((vL + vR) + vB) + vT) + alpha * d) * beta; /* :313 */
       } else {
         float o = 0.0f;
-        if (x == 0) o = -texel1(p_in, n, x + 1, y);     /* :319 */
-        if (x == n - 1) o = -texel1(p_in, n, x - 1, y); /* :320 */
-        if (y == 0) o = -texel1(p_in, n, x, y + 1);     /* :321 */
-        if (y == n - 1) o = -texel1(p_in, n, x, y - 1); /* :322 */
+        if (x == 0) o = -texel1(p_in, nx, ny, x + 1, y);     /* :319 */
+        if (x == nx - 1) o = -texel1(p_in, nx, ny, x - 1, y); /* :320 */
+        if (y == 0) o = -texel1(p_in, nx, ny, x, y + 1);     /* :321 */
+        if (y == ny - 1) o = -texel1(p_in, nx, ny, x, y - 1); /* :322 */
         p_out[id] = o;
       }
     }
 }
 
 /* kernel.cu:326-355 */
-void ref_projection(int n, const float *vel_in, const float *p, float *vel_out) {
+void ref_projection_rect(int nx, int ny, const float *vel_in, const float *p, float *vel_out) {
   const f2 *vin = (const f2 *)vel_in;
   f2 *vout = (f2 *)vel_out;
   OMP_ROWS
-  for (int y = 0; y < n; ++y)
-    for (int x = 0; x < n; ++x) {
-      size_t id = x + (size_t)y * n;
-      if (interior(x, y, n)) {
-        float pL = p[id - 1], pR = p[id + 1], pB = p[id - n], pT = p[id + n];
+  for (int y = 0; y < ny; ++y)
+    for (int x = 0; x < nx; ++x) {
+      size_t id = x + (size_t)y * nx;
+      if (interior(x, y, nx, ny)) {
+        float pL = p[id - 1], pR = p[id + 1], pB = p[id - nx], pT = p[id + nx];
         f2 v = vin[id];
         f2 o = { v.x - (pR - pL), v.y - (pT - pB) }; /* :344 */
         vout[id] = o;
       } else {
         f2 o = { 0.0f, 0.0f };
-        if (x == 0) o = neg2(texel2(vin, n, x + 1, y));         /* :350 */
-        if (x == n - 1) o = neg2(texel2(vin, n, x - 1, y));     /* :351 */
-        if (y == 0) o = neg2(texel2(vin, n, x + 1, y + 1));     /* :352 */
-        if (y == n - 1) o = neg2(texel2(vin, n, x + 1, y - 1)); /* :353 */
+        if (x == 0) o = neg2(texel2(vin, nx, ny, x + 1, y));         /* :350 */
+        if (x == nx - 1) o = neg2(texel2(vin, nx, ny, x - 1, y));     /* :351 */
+        if (y == 0) o = neg2(texel2(vin, nx, ny, x + 1, y + 1));     /* :352 */
+        if (y == ny - 1) o = neg2(texel2(vin, nx, ny, x + 1, y - 1)); /* :353 */
         vout[id] = o;
       }
     }
 }
 
 /* kernel.cu:357-383 */
-void ref_add_force(int n, float dt, float radius, float sx, float sy, float fx, float fy,
+void ref_add_force_rect(int nx, int ny, float dt, float radius, float sx, float sy, float fx, float fy,
                    const float rgba[4], float *vel, float *dens) {
   f2 *v = (f2 *)vel;
   f4 *d = (f4 *)dens;
   OMP_ROWS
-  for (int y = 0; y < n; ++y)
-    for (int x = 0; x < n; ++x) {
-      size_t id = x + (size_t)y * n;
-      float dx = ((float)x / (float)n) - sx; /* :365 */
-      float dy = ((float)y / (float)n) - sy; /* :366 */
+  for (int y = 0; y < ny; ++y)
+    for (int x = 0; x < nx; ++x) {
+      size_t id = x + (size_t)y * nx;
+      float dx = ((float)x / (float)nx) - sx; /* :365 */
+      float dy = ((float)y / (float)ny) - sy; /* :366 */
       float c = expf(-(dx * dx + dy * dy) / radius) * dt; /* :370 (float overload of exp) */
       v[id].x = v[id].x + c * fx; /* :378 */
       v[id].y = v[id].y + c * fy;
@@ -310,12 +310,37 @@ void ref_add_force(int n, float dt, float radius, float sx, float sy, float fx, 
     }
 }
 
+/* The reference's kernels take ONE gridResolution for both axes (kernel.cu:115, :143, :174, :266,
+ * :292, :327, :358, :438): these are the restatements proper.  The *_rect forms above are the
+ * same rules with the extent taken per axis (x tests and clamps against nx, y tests and clamps
+ * against ny, row pitch nx, add_force normalises x by nx and y by ny) - the generalisation
+ * SURVEY.md 8f-4 asks for, with no behaviour of the reference to be identical to when nx != ny. */
+void ref_advection(int n, float dt, const float *vel_in, float *vel_out) { ref_advection_rect(n, n, dt, vel_in, vel_out); }
+void ref_advection_density(int n, float dt, const float *vel, const float *dens_in, float *dens_out) {
+  ref_advection_density_rect(n, n, dt, vel, dens_in, dens_out);
+}
+void ref_diffusion(int n, float dt, float viscosity, const float *vel_in, float *vel_out) {
+  ref_diffusion_rect(n, n, dt, viscosity, vel_in, vel_out);
+}
+void ref_vorticity(int n, const float *vel, float *vort) { ref_vorticity_rect(n, n, vel, vort); }
+void ref_add_vorticity(int n, float dt, const float *vort, float *vel) { ref_add_vorticity_rect(n, n, dt, vort, vel); }
+void ref_divergence(int n, const float *vel, float *div) { ref_divergence_rect(n, n, vel, div); }
+void ref_pressure_jacobi(int n, const float *p_in, const float *div, float *p_out) {
+  ref_pressure_jacobi_rect(n, n, p_in, div, p_out);
+}
+void ref_projection(int n, const float *vel_in, const float *p, float *vel_out) { ref_projection_rect(n, n, vel_in, p, vel_out); }
+void ref_add_force(int n, float dt, float radius, float sx, float sy, float fx, float fy, const float rgba[4],
+                   float *vel, float *dens) {
+  ref_add_force_rect(n, n, dt, radius, sx, sy, fx, fy, rgba, vel, dens);
+}
+
 /* ------------------------------------------------------------------------- */
 /* host driver: the reference's L2 layer (kernel.cu:435-708) behind fluid.h   */
 /* ------------------------------------------------------------------------- */
 
 struct fluid_ctx {
   fluid_params prm;
+  int nx, ny; /* grid extent: prm.n columns, prm.ny rows (0 = square, the reference's case) */
   size_t cells;
   float *vel[2];  /* velocityBufferArray[2]  kernel.cu:443-444 */
   float *dens[2]; /* densityBufferArray[2]   :447-448 */
@@ -342,11 +367,14 @@ int fluid_init(fluid_ctx **out, const fluid_params *p) {
   fluid_params prm;
   if (p) prm = *p; else fluid_default_params(&prm);
   if (prm.n < 4 || prm.diffusion_iters < 0 || prm.pressure_iters < 0) return FLUID_E_INVALID;
+  if (prm.ny != 0 && prm.ny < 4) return FLUID_E_INVALID;
   if (prm.slab_count > 1) return FLUID_E_UNSUPPORTED; /* the oracle is whole-domain only */
   fluid_ctx *c = (fluid_ctx *)calloc(1, sizeof *c);
   if (!c) return FLUID_E_NOMEM;
   c->prm = prm;
-  c->cells = (size_t)prm.n * prm.n;
+  c->nx = prm.n;
+  c->ny = prm.ny ? prm.ny : prm.n;
+  c->cells = (size_t)c->nx * c->ny;
   int ok = 1;
   for (int i = 0; i < 2; ++i) {
     ok &= (c->vel[i] = (float *)calloc(c->cells, 2 * sizeof(float))) != NULL;
@@ -389,7 +417,7 @@ static void reset_pressure(fluid_ctx *c) {
 int fluid_advect_velocity(fluid_ctx *c) {
   if (!c) return FLUID_E_INVALID;
   int nxt = (c->vin + 1) % 2;
-  ref_advection(c->prm.n, c->prm.dt, c->vel[c->vin], c->vel[nxt]);
+  ref_advection_rect(c->nx, c->ny, c->prm.dt, c->vel[c->vin], c->vel[nxt]);
   c->vin = nxt;
   return FLUID_OK;
 }
@@ -399,7 +427,7 @@ int fluid_diffuse(fluid_ctx *c) {
   if (!c) return FLUID_E_INVALID;
   for (int i = 0; i < c->prm.diffusion_iters; ++i) {
     int nxt = (c->vin + 1) % 2;
-    ref_diffusion(c->prm.n, c->prm.dt, c->prm.viscosity, c->vel[c->vin], c->vel[nxt]);
+    ref_diffusion_rect(c->nx, c->ny, c->prm.dt, c->prm.viscosity, c->vel[c->vin], c->vel[nxt]);
     c->vin = nxt;
   }
   return FLUID_OK;
@@ -408,23 +436,23 @@ int fluid_diffuse(fluid_ctx *c) {
 /* kernel.cu:557-580 */
 int fluid_vorticity(fluid_ctx *c) {
   if (!c) return FLUID_E_INVALID;
-  ref_vorticity(c->prm.n, c->vel[c->vin], c->vort);
-  ref_add_vorticity(c->prm.n, c->prm.dt, c->vort, c->vel[c->vin]);
+  ref_vorticity_rect(c->nx, c->ny, c->vel[c->vin], c->vort);
+  ref_add_vorticity_rect(c->nx, c->ny, c->prm.dt, c->vort, c->vel[c->vin]);
   return FLUID_OK;
 }
 
 /* kernel.cu:604-662 */
 int fluid_project(fluid_ctx *c) {
   if (!c) return FLUID_E_INVALID;
-  ref_divergence(c->prm.n, c->vel[c->vin], c->div); /* :607-616 */
+  ref_divergence_rect(c->nx, c->ny, c->vel[c->vin], c->div); /* :607-616 */
   reset_pressure(c);                                /* :618 */
   for (int i = 0; i < c->prm.pressure_iters; ++i) { /* :620-641 */
     int nxt = (c->pin + 1) % 2;
-    ref_pressure_jacobi(c->prm.n, c->prs[c->pin], c->div, c->prs[nxt]);
+    ref_pressure_jacobi_rect(c->nx, c->ny, c->prs[c->pin], c->div, c->prs[nxt]);
     c->pin = nxt;
   }
   int nxt = (c->vin + 1) % 2; /* :643-661 */
-  ref_projection(c->prm.n, c->vel[c->vin], c->prs[c->pin], c->vel[nxt]);
+  ref_projection_rect(c->nx, c->ny, c->vel[c->vin], c->prs[c->pin], c->vel[nxt]);
   c->vin = nxt;
   return FLUID_OK;
 }
@@ -433,7 +461,7 @@ int fluid_project(fluid_ctx *c) {
 int fluid_advect_density(fluid_ctx *c) {
   if (!c) return FLUID_E_INVALID;
   int nxt = (c->din + 1) % 2;
-  ref_advection_density(c->prm.n, c->prm.dt, c->vel[c->vin], c->dens[c->din], c->dens[nxt]);
+  ref_advection_density_rect(c->nx, c->ny, c->prm.dt, c->vel[c->vin], c->dens[c->din], c->dens[nxt]);
   c->din = nxt;
   return FLUID_OK;
 }
@@ -456,7 +484,7 @@ int fluid_prepare_steps(fluid_ctx *c, int nsteps) { return c && nsteps >= 0 ? FL
 
 int fluid_add_source(fluid_ctx *c, float sx, float sy, float fx, float fy, const float rgba[4]) {
   if (!c || !rgba) return FLUID_E_INVALID;
-  ref_add_force(c->prm.n, c->prm.dt, c->prm.splat_radius, sx, sy, fx, fy, rgba, c->vel[c->vin],
+  ref_add_force_rect(c->nx, c->ny, c->prm.dt, c->prm.splat_radius, sx, sy, fx, fy, rgba, c->vel[c->vin],
                 c->dens[c->din]);
   return FLUID_OK;
 }
@@ -500,18 +528,18 @@ int fluid_sync(fluid_ctx *c) { return c ? FLUID_OK : FLUID_E_INVALID; }
 static float max_nan(float a, float b) { return (b > a || b != b) ? b : a; }
 int fluid_diagnostics(fluid_ctx *c, fluid_diag *out) {
   if (!c || !out) return FLUID_E_INVALID;
-  const int n = c->prm.n;
+  const int n = c->nx, ny = c->ny;
   const float *v = c->vel[c->vin], *d = c->dens[c->din], *p = c->prs[c->pin], *dv = c->div;
   float mx[6] = {0, 0, 0, 0, 0, 0};
   double sm[4] = {0, 0, 0, 0};
-  for (int y = 0; y < n; ++y)
+  for (int y = 0; y < ny; ++y)
     for (int x = 0; x < n; ++x) {
       const size_t id = (size_t)y * n + x;
       mx[0] = max_nan(mx[0], fabsf(v[2 * id]));
       mx[1] = max_nan(mx[1], fabsf(v[2 * id + 1]));
       mx[2] = max_nan(mx[2], fabsf(dv[id]));
       mx[3] = max_nan(mx[3], fabsf(p[id]));
-      if (x >= 1 && x <= n - 2 && y >= 1 && y <= n - 2) {
+      if (x >= 1 && x <= n - 2 && y >= 1 && y <= ny - 2) {
         const float vL = p[id - 1], vR = p[id + 1], vB = p[id - n], vT = p[id + n];
         const float next = ((((vL + vR) + vB) + vT) + (-1.0f) * dv[id]) * 0.25f; /* kernel.cu:313 */
         mx[4] = max_nan(mx[4], fabsf(next - p[id]));
@@ -533,9 +561,9 @@ int fluid_diagnostics(fluid_ctx *c, fluid_diag *out) {
 
 int fluid_geometry(const fluid_ctx *c, int *n, int *row0, int *rows) {
   if (!c) return FLUID_E_INVALID;
-  if (n) *n = c->prm.n;
+  if (n) *n = c->nx;
   if (row0) *row0 = 0;
-  if (rows) *rows = c->prm.n;
+  if (rows) *rows = c->ny;
   return FLUID_OK;
 }
 

