@@ -23,7 +23,9 @@ import time
 
 def default_modes():
     rehearsal = os.environ.get("FLUID_BENCH_BACKEND", "nccl") != "nccl"
-    return "staged,torch" if rehearsal else "rccl-graph,rccl,torch"
+    # last resort on a node whose RCCL does not come up at all: the library-driven exchange with the
+    # bytes staged through the host (slow, and labelled as such in the line)
+    return "staged,torch" if rehearsal else "rccl-graph,rccl,torch,staged"
 
 
 def rendezvous_wait(attempt, limit):
@@ -98,6 +100,7 @@ def run_multi(pkg, args, n, D, J, flags):
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
                          f"--nproc-per-node {args.gpus}, or with no launcher at all")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # one node by contract; the host name may not resolve
     # FLUID_BENCH_BACKEND=gloo + FLUID_BENCH_ONE_GPU=1: rehearsal of this code path with several
     # ranks on a single GPU (RCCL refuses two ranks per device); never the measured configuration.
     backend = os.environ.get("FLUID_BENCH_BACKEND", "nccl")
@@ -232,7 +235,7 @@ def run_multi(pkg, args, n, D, J, flags):
         bpc = pkg.alg_bytes_per_cell(D, J)
         carrier = {"rccl-graph": "RCCL ncclSend/ncclRecv posted by the library, whole steps replayed as hipGraphs",
                    "rccl": "RCCL ncclSend/ncclRecv posted by the library, steps enqueued directly",
-                   "staged": "host-staged rehearsal transport (one GPU), exchange posted by the library",
+                   "staged": "host-staged transport (gloo through host memory; rehearsal / last resort), exchange posted by the library",
                    "torch": "torch.distributed P2P (" + ("RCCL" if backend == "nccl" else backend) + "), step driven in parts from Python",
                    "torch-plain": "torch.distributed P2P, exchange before the step, no overlap"}[mode]
         out = {

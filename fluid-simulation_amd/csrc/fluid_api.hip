@@ -90,6 +90,7 @@ struct fluid_ctx {
   std::map<int, GraphEntry> graphs;
   // temporal-blocking plan (fused path): sweeps per launch, columns per lane, target waves
   int tb_kj = 10, tb_kd = 5, tb_cj = 2, tb_cd = 2, tb_waves = 8192, tb_minchunk = 4;
+  int tile_ty = 32;   // rows an LDS tile stores (16 on the smallest grids, see fluid_init)
   bool tile = false;  // small grids: LDS-tiled sweeps (fluid_kernels_tile.hip) instead of the register pipeline
   bool nt_stores = false;  // grids far beyond the caches: non-temporal stores in the two streaming kernels
   int graph_steps = 1;     // whole steps captured per graph (fluid_step)
@@ -317,7 +318,7 @@ void enq_diffuse(fluid_ctx *c, int out_m) {
       const int k = next_pass(c, left, true);
       ProfScope p(c, K_DIFFUSE_TILE, 16.0 * k * cells, 16.0 * cells);
       const Range r = widened(c, out_m + left - k);
-      LAUNCH(c, launch_diffuse_tile(c->stream, c->g, r.r0, r.r1, k, c->alpha, c->beta, c->vel[c->vin], c->vel[c->vin ^ 1]));
+      LAUNCH(c, launch_diffuse_tile(c->stream, c->g, r.r0, r.r1, k, c->tile_ty, c->alpha, c->beta, c->vel[c->vin], c->vel[c->vin ^ 1]));
       c->vin ^= 1;
       left -= k;
     }
@@ -382,11 +383,11 @@ void enq_pressure_group(fluid_ctx *c, int g) {
       if (first) {
         ProfScope p(c, K_JACOBI_DIV_TILE, 12.0 * cells + 12.0 * k * cells, 16.0 * cells);  // velocity in, divergence and p out
         const Range r = widened(c, div_m >= 0 ? div_m : 1 + left - k);
-        LAUNCH(c, launch_jacobi_div_tile(c->stream, c->g, r.r0, r.r1, k, c->vel[c->vin], c->div, c->prs[c->pin ^ 1]));
+        LAUNCH(c, launch_jacobi_div_tile(c->stream, c->g, r.r0, r.r1, k, c->tile_ty, c->vel[c->vin], c->div, c->prs[c->pin ^ 1]));
       } else {
         ProfScope p(c, K_JACOBI_TILE, 12.0 * k * cells, 12.0 * cells);
         const Range r = widened(c, 1 + left - k);
-        LAUNCH(c, launch_jacobi_tile(c->stream, c->g, r.r0, r.r1, k, c->prs[c->pin], c->div, c->prs[c->pin ^ 1]));
+        LAUNCH(c, launch_jacobi_tile(c->stream, c->g, r.r0, r.r1, k, c->tile_ty, c->prs[c->pin], c->div, c->prs[c->pin ^ 1]));
       }
       first = false;
       c->pin ^= 1;
@@ -739,6 +740,11 @@ int fluid_init(fluid_ctx **out, const fluid_params *p) {
   const long long owned = (long long)prm.n * si.rows;
   c->tile = env_int("FLUID_TILE", owned <= (1ll << 20) ? 1 : 0) != 0;
   c->tb_minchunk = 1;
+  // 64 x 32 tiles of a 512^2 grid are 128 workgroups on 256 CUs, and a tile's 10 sweeps are a latency
+  // chain of about 13 us whatever the grid: 16-row tiles there (512^2, J = 10: 33.4 -> 29.6 us per step,
+  // J = 40: 57.9 -> 51.5; slower from 768^2 up, where 32-row tiles already give every CU work)
+  c->tile_ty = env_int("FLUID_TILE_TY", owned <= 3 * (1ll << 17) ? 16 : 32);
+  if (!tile_has_ty(c->tile_ty)) c->tile_ty = 32;
   if (c->tile) { c->tb_kj = 10; c->tb_kd = 10; }
   else if (owned < (1ll << 23)) { c->tb_kj = 8; c->tb_kd = 10; c->tb_waves = 2048; }
   else if (owned < (1ll << 24)) { c->tb_kj = 8; c->tb_kd = 5; c->tb_waves = 3900; }

@@ -80,12 +80,14 @@ bool launch_diffuse_tb(hipStream_t s, Geom g, int r0, int r1, int k, int cols, i
 
 // ---- LDS-tiled sweeps for small grids (fluid_kernels_tile.hip) ---------------
 // k sweeps per launch on local rows [r0, r1); false when k is not instantiated.
+// ty: rows a workgroup stores (16 or 32, tile_has_ty).
 bool tile_has_k(int k, bool float2_field);
-bool launch_jacobi_tile(hipStream_t s, Geom g, int r0, int r1, int k, const float *pin, const float *div,
+bool tile_has_ty(int ty);
+bool launch_jacobi_tile(hipStream_t s, Geom g, int r0, int r1, int k, int ty, const float *pin, const float *div,
                         float *pout);
-bool launch_jacobi_div_tile(hipStream_t s, Geom g, int r0, int r1, int k, const float2 *vel, float *div_out,
+bool launch_jacobi_div_tile(hipStream_t s, Geom g, int r0, int r1, int k, int ty, const float2 *vel, float *div_out,
                             float *pout);
-bool launch_diffuse_tile(hipStream_t s, Geom g, int r0, int r1, int k, float alpha, float beta,
+bool launch_diffuse_tile(hipStream_t s, Geom g, int r0, int r1, int k, int ty, float alpha, float beta,
                          const float2 *vin, float2 *vout);
 
 // ---- diagnostics (fluid_kernels_diag.hip) -----------------------------------

@@ -18,7 +18,9 @@ namespace {
 #ifndef TILE_TX
 #define TILE_TX 64
 #endif
-constexpr int TX = TILE_TX, TY = 32;  // cells a workgroup stores
+constexpr int TX = TILE_TX;  // columns a workgroup stores; it stores TY rows (32, or 16 on the smallest grids:
+                             // a tile's sweep is a latency chain of about 1.3 us whatever the grid, so when 64 x 32
+                             // tiles do not even give every CU one, shorter tiles are what shortens the launch)
 constexpr int R = 2;                   // rows of a thread's run
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
@@ -26,7 +28,7 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v,
 // Tile geometry: K halo rows above and below, HX = K rounded up to a multiple of four halo
 // columns left and right, so that the tile and its stored centre are whole 4-float segments
 // (16-byte LDS and global accesses).  A thread owns a run of R vertically adjacent segments.
-template <int K> struct TileGeom {
+template <int K, int TY> struct TileGeom {
   static constexpr int HX = (K + 3) & ~3;
   static constexpr int W = TX + 2 * HX, H = TY + 2 * K, W4 = W / 4;
   static constexpr int RUNS = (H / R) * W4;
@@ -84,7 +86,7 @@ enum TileMode {
 };
 
 // Where a thread's run sits.
-template <int K> struct Run {
+template <int K, int TY> struct Run {
   int c0;      // LDS index of the run's first segment
   int cm, cp;  // LDS index of the segment above the run / below it (clamped into the tile)
   int x, y;    // global coordinates of the run's first cell
@@ -93,7 +95,7 @@ template <int K> struct Run {
   // row j of the run is row 0 / row n-1; the segment lies inside the domain in x
   bool bx0, bx1, by0[R], by1[R], yb, in_x;
   __device__ __forceinline__ void locate(int x_org, int y_org, int n, int ny) {
-    using G = TileGeom<K>;
+    using G = TileGeom<K, TY>;
     const int run = threadIdx.x;
     const int rr = run / G::W4, sx = run - rr * G::W4, ly0 = rr * R;
     active = run < G::RUNS;
@@ -120,11 +122,11 @@ template <int K> struct Run {
 // One sweep of one plane: the run's cells stay in registers (ce) from sweep to sweep; the rows
 // above and below the run and the cells left and right of it come from LDS (a), the new values
 // go to LDS (b) for the neighbours.
-template <int K, class Rule>
-__device__ __forceinline__ void run_sweep(const float *__restrict__ a, float *__restrict__ b, const Run<K> &rn,
+template <int K, int TY, class Rule>
+__device__ __forceinline__ void run_sweep(const float *__restrict__ a, float *__restrict__ b, const Run<K, TY> &rn,
                                           F4 (&ce)[R], const F4 (&aux)[R], int mode, int n, int ny, float alpha,
                                           float beta) {
-  using G = TileGeom<K>;
+  using G = TileGeom<K, TY>;
   const F4 rm = ld4(a + rn.cm), rp = ld4(a + rn.cp);
   float l[R], r[R];
 #pragma unroll
@@ -180,9 +182,9 @@ __device__ __forceinline__ void run_sweep(const float *__restrict__ a, float *__
 }
 
 // Is this one of the cells the workgroup stores?  (whole segments: HX and TX are multiples of 4)
-template <int K>
-__device__ __forceinline__ bool stored_segment(const Run<K> &rn, int j, int x_org, int y_org, int y1, int n) {
-  using G = TileGeom<K>;
+template <int K, int TY>
+__device__ __forceinline__ bool stored_segment(const Run<K, TY> &rn, int j, int x_org, int y_org, int y1, int n) {
+  using G = TileGeom<K, TY>;
   const int lx = rn.x - x_org, ly = rn.y + j - y_org;
   return rn.active && lx >= G::HX && lx < G::HX + TX && ly >= K && ly < K + TY && rn.y + j < y1 && rn.x < n;
 }
@@ -196,14 +198,14 @@ __device__ __forceinline__ bool stored_segment(const Run<K> &rn, int j, int x_or
 // rules read inward only.  A tile that touches a domain border or rows that are not stored
 // (slab) still moves whole segments and applies the border rules by side (TileMode); only a grid
 // that is not a multiple of four wide takes the element-wise path.
-template <int K, bool WITH_DIV>
-__global__ __launch_bounds__(TileGeom<K>::THREADS) void k_jacobi_tile(Geom g, int r0, int r1,
+template <int K, bool WITH_DIV, int TY>
+__global__ __launch_bounds__((TileGeom<K, TY>::THREADS)) void k_jacobi_tile(Geom g, int r0, int r1,
                                                                       const float *__restrict__ pin,
                                                                       const float2 *__restrict__ vel,
                                                                       const float *__restrict__ div_in,
                                                                       float *__restrict__ div_out,
                                                                       float *__restrict__ pout) {
-  using G = TileGeom<K>;
+  using G = TileGeom<K, TY>;
   __shared__ __attribute__((aligned(16))) float lds[2 * G::PLANE];
   float *a = lds + 4, *b = lds + G::PLANE + 4;
   const int n = g.n;
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(TileGeom<K>::THREADS) void k_jacobi_tile(Geom g, in
   const bool edge = x_org <= 0 || x_org + G::W >= n || y_org <= 0 || y_org + G::H >= g.ny || r_org < RM ||
                     r_org + G::H > g.L - RM;
   const int mode = (n & 3) ? TILE_CELLS : edge ? TILE_BORDER : TILE_INSIDE;
-  Run<K> rn;
+  Run<K, TY> rn;
   rn.locate(x_org, y_org, n, g.ny);
   F4 ce[R], dv[R];
   const F4 zero = F4{{0.0f, 0.0f, 0.0f, 0.0f}};
@@ -278,7 +280,7 @@ __global__ __launch_bounds__(TileGeom<K>::THREADS) void k_jacobi_tile(Geom g, in
       }
     }
     if (rn.active) st4(a + rn.c0 + j * G::W, ce[j]);
-    if (WITH_DIV && stored_segment<K>(rn, j, x_org, y_org, g.ybase + r1, n)) {
+    if (WITH_DIV && stored_segment<K, TY>(rn, j, x_org, y_org, g.ybase + r1, n)) {
       if (mode != TILE_CELLS) {
         st4(div_out + (size_t)rl * n + rn.x, dv[j]);
       } else {
@@ -291,13 +293,13 @@ __global__ __launch_bounds__(TileGeom<K>::THREADS) void k_jacobi_tile(Geom g, in
   __syncthreads();
 #pragma unroll 1
   for (int s = 0; s < K; ++s) {
-    if (rn.active) run_sweep<K, JacobiRule>(a, b, rn, ce, dv, mode, n, g.ny, 0.0f, 0.0f);
+    if (rn.active) run_sweep<K, TY, JacobiRule>(a, b, rn, ce, dv, mode, n, g.ny, 0.0f, 0.0f);
     __syncthreads();
     float *t = a; a = b; b = t;
   }
 #pragma unroll
   for (int j = 0; j < R; ++j) {
-    if (!stored_segment<K>(rn, j, x_org, y_org, g.ybase + r1, n)) continue;
+    if (!stored_segment<K, TY>(rn, j, x_org, y_org, g.ybase + r1, n)) continue;
     const size_t id = (size_t)(rn.y + j - g.ybase) * n + rn.x;
     if (mode != TILE_CELLS) {
       st4(pout + id, ce[j]);
@@ -310,12 +312,12 @@ __global__ __launch_bounds__(TileGeom<K>::THREADS) void k_jacobi_tile(Geom g, in
 }
 
 // K diffusion sweeps; the two velocity components are two planes.
-template <int K>
-__global__ __launch_bounds__(TileGeom<K>::THREADS) void k_diffuse_tile(Geom g, int r0, int r1, float alpha,
+template <int K, int TY>
+__global__ __launch_bounds__((TileGeom<K, TY>::THREADS)) void k_diffuse_tile(Geom g, int r0, int r1, float alpha,
                                                                        float beta,
                                                                        const float2 *__restrict__ vin,
                                                                        float2 *__restrict__ vout) {
-  using G = TileGeom<K>;
+  using G = TileGeom<K, TY>;
   // four planes; dynamic because the deep tiles need more than the 64 KB static LDS limit
   extern __shared__ __attribute__((aligned(16))) float tile_lds[];
   float *au = tile_lds + 4, *aw = au + G::PLANE, *bu = aw + G::PLANE, *bw = bu + G::PLANE;
@@ -326,7 +328,7 @@ __global__ __launch_bounds__(TileGeom<K>::THREADS) void k_diffuse_tile(Geom g, i
   const bool edge = x_org <= 0 || x_org + G::W >= n || y_org <= 0 || y_org + G::H >= g.ny || r_org < 0 ||
                     r_org + G::H > g.L;
   const int mode = (n & 3) ? TILE_CELLS : edge ? TILE_BORDER : TILE_INSIDE;
-  Run<K> rn;
+  Run<K, TY> rn;
   rn.locate(x_org, y_org, n, g.ny);
   F4 cu[R], cw[R], none[R];
 #pragma unroll
@@ -358,8 +360,8 @@ __global__ __launch_bounds__(TileGeom<K>::THREADS) void k_diffuse_tile(Geom g, i
 #pragma unroll 1
   for (int s = 0; s < K; ++s) {
     if (rn.active) {
-      run_sweep<K, DiffuseRule>(au, bu, rn, cu, none, mode, n, g.ny, alpha, beta);
-      run_sweep<K, DiffuseRule>(aw, bw, rn, cw, none, mode, n, g.ny, alpha, beta);
+      run_sweep<K, TY, DiffuseRule>(au, bu, rn, cu, none, mode, n, g.ny, alpha, beta);
+      run_sweep<K, TY, DiffuseRule>(aw, bw, rn, cw, none, mode, n, g.ny, alpha, beta);
     }
     __syncthreads();
     float *t = au; au = bu; bu = t;
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(TileGeom<K>::THREADS) void k_diffuse_tile(Geom g, i
   }
 #pragma unroll
   for (int j = 0; j < R; ++j) {
-    if (!stored_segment<K>(rn, j, x_org, y_org, g.ybase + r1, n)) continue;
+    if (!stored_segment<K, TY>(rn, j, x_org, y_org, g.ybase + r1, n)) continue;
     const size_t id = (size_t)(rn.y + j - g.ybase) * n + rn.x;
     if (mode != TILE_CELLS) {
       float *q = reinterpret_cast<float *>(vout + id);
@@ -381,77 +383,96 @@ __global__ __launch_bounds__(TileGeom<K>::THREADS) void k_diffuse_tile(Geom g, i
   }
 }
 
-inline dim3 tile_grid(Geom g, int r0, int r1) { return dim3((g.n + TX - 1) / TX, (r1 - r0 + TY - 1) / TY); }
+inline dim3 tile_grid(Geom g, int r0, int r1, int ty) { return dim3((g.n + TX - 1) / TX, (r1 - r0 + ty - 1) / ty); }
 
 }  // namespace
 
-// Sweep counts instantiated: the LDS tile grows with K (two planes of (TX + 2 HX) x (32 + 2K)
-// floats for the pressure, four for the velocity).
+// Sweep counts instantiated: the LDS tile grows with K (two planes of (TX + 2 HX) x (TY + 2K)
+// floats for the pressure, four for the velocity).  Tile heights: 32 and 16 rows.
 bool tile_has_k(int k, bool) {
   switch (k) {
     case 1: case 2: case 4: case 5: case 8: case 10: return true;
     default: return false;
   }
 }
+bool tile_has_ty(int ty) { return ty == 16 || ty == 32; }
 
-#define TILE_JACOBI_CASE(K_, DIV_)                                                                  \
-  case K_:                                                                                         \
-    k_jacobi_tile<K_, DIV_><<<tile_grid(g, r0, r1), TileGeom<K_>::THREADS, 0, s>>>(g, r0, r1, pin, vel, div_in, \
-                                                                                  div_out, pout);  \
-    return true;
+template <int K, bool DIV, int TY>
+void jacobi_tile_launch(hipStream_t s, Geom g, int r0, int r1, const float *pin, const float2 *vel, const float *div_in,
+                        float *div_out, float *pout) {
+  k_jacobi_tile<K, DIV, TY><<<tile_grid(g, r0, r1, TY), TileGeom<K, TY>::THREADS, 0, s>>>(g, r0, r1, pin, vel, div_in,
+                                                                                          div_out, pout);
+}
+template <int K, bool DIV>
+bool jacobi_tile_ty(hipStream_t s, Geom g, int r0, int r1, int ty, const float *pin, const float2 *vel,
+                    const float *div_in, float *div_out, float *pout) {
+  if (ty == 16) jacobi_tile_launch<K, DIV, 16>(s, g, r0, r1, pin, vel, div_in, div_out, pout);
+  else if (ty == 32) jacobi_tile_launch<K, DIV, 32>(s, g, r0, r1, pin, vel, div_in, div_out, pout);
+  else return false;
+  return true;
+}
+template <bool DIV>
+bool jacobi_tile_k(hipStream_t s, Geom g, int r0, int r1, int k, int ty, const float *pin, const float2 *vel,
+                   const float *div_in, float *div_out, float *pout) {
+  switch (k) {
+    case 1: return jacobi_tile_ty<1, DIV>(s, g, r0, r1, ty, pin, vel, div_in, div_out, pout);
+    case 2: return jacobi_tile_ty<2, DIV>(s, g, r0, r1, ty, pin, vel, div_in, div_out, pout);
+    case 4: return jacobi_tile_ty<4, DIV>(s, g, r0, r1, ty, pin, vel, div_in, div_out, pout);
+    case 5: return jacobi_tile_ty<5, DIV>(s, g, r0, r1, ty, pin, vel, div_in, div_out, pout);
+    case 8: return jacobi_tile_ty<8, DIV>(s, g, r0, r1, ty, pin, vel, div_in, div_out, pout);
+    case 10: return jacobi_tile_ty<10, DIV>(s, g, r0, r1, ty, pin, vel, div_in, div_out, pout);
+    default: return false;
+  }
+}
 
-bool launch_jacobi_tile(hipStream_t s, Geom g, int r0, int r1, int k, const float *pin, const float *div_in,
+bool launch_jacobi_tile(hipStream_t s, Geom g, int r0, int r1, int k, int ty, const float *pin, const float *div_in,
                         float *pout) {
   if (r1 <= r0) return true;
-  const float2 *vel = nullptr;
-  float *div_out = nullptr;
-  switch (k) {
-    TILE_JACOBI_CASE(1, false) TILE_JACOBI_CASE(2, false) TILE_JACOBI_CASE(4, false)
-    TILE_JACOBI_CASE(5, false) TILE_JACOBI_CASE(8, false) TILE_JACOBI_CASE(10, false)
-    default: return false;
-  }
+  return jacobi_tile_k<false>(s, g, r0, r1, k, ty, pin, nullptr, div_in, nullptr, pout);
 }
 
-bool launch_jacobi_div_tile(hipStream_t s, Geom g, int r0, int r1, int k, const float2 *vel, float *div_out,
+bool launch_jacobi_div_tile(hipStream_t s, Geom g, int r0, int r1, int k, int ty, const float2 *vel, float *div_out,
                             float *pout) {
   if (r1 <= r0) return true;
-  const float *pin = nullptr, *div_in = nullptr;
-  switch (k) {
-    TILE_JACOBI_CASE(1, true) TILE_JACOBI_CASE(2, true) TILE_JACOBI_CASE(4, true)
-    TILE_JACOBI_CASE(5, true) TILE_JACOBI_CASE(8, true) TILE_JACOBI_CASE(10, true)
-    default: return false;
-  }
+  return jacobi_tile_k<true>(s, g, r0, r1, k, ty, nullptr, vel, nullptr, div_out, pout);
 }
 
-template <int K>
+template <int K, int TY>
 bool diffuse_tile_launch(hipStream_t s, Geom g, int r0, int r1, float alpha, float beta, const float2 *vin,
                          float2 *vout) {
-  using G = TileGeom<K>;
+  using G = TileGeom<K, TY>;
   constexpr size_t bytes = 4 * (size_t)G::PLANE * sizeof(float);
   // more than 64 KB of LDS per workgroup is an opt-in, once per kernel AND device (a context on
   // another device, fluid_params.device, has its own copy of the code object)
   static bool raised[64] = {false};
   int dev = 0;
   if (bytes > 64 * 1024 && (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || !raised[dev])) {
-    if (hipFuncSetAttribute((const void *)k_diffuse_tile<K>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute((const void *)k_diffuse_tile<K, TY>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)bytes) != hipSuccess)
       return false;
     if (dev >= 0 && dev < 64) raised[dev] = true;
   }
-  k_diffuse_tile<K><<<tile_grid(g, r0, r1), G::THREADS, bytes, s>>>(g, r0, r1, alpha, beta, vin, vout);
+  k_diffuse_tile<K, TY><<<tile_grid(g, r0, r1, TY), G::THREADS, bytes, s>>>(g, r0, r1, alpha, beta, vin, vout);
   return true;
 }
+template <int K>
+bool diffuse_tile_ty(hipStream_t s, Geom g, int r0, int r1, int ty, float alpha, float beta, const float2 *vin,
+                     float2 *vout) {
+  if (ty == 16) return diffuse_tile_launch<K, 16>(s, g, r0, r1, alpha, beta, vin, vout);
+  if (ty == 32) return diffuse_tile_launch<K, 32>(s, g, r0, r1, alpha, beta, vin, vout);
+  return false;
+}
 
-bool launch_diffuse_tile(hipStream_t s, Geom g, int r0, int r1, int k, float alpha, float beta,
+bool launch_diffuse_tile(hipStream_t s, Geom g, int r0, int r1, int k, int ty, float alpha, float beta,
                          const float2 *vin, float2 *vout) {
   if (r1 <= r0) return true;
   switch (k) {
-    case 1: return diffuse_tile_launch<1>(s, g, r0, r1, alpha, beta, vin, vout);
-    case 2: return diffuse_tile_launch<2>(s, g, r0, r1, alpha, beta, vin, vout);
-    case 4: return diffuse_tile_launch<4>(s, g, r0, r1, alpha, beta, vin, vout);
-    case 5: return diffuse_tile_launch<5>(s, g, r0, r1, alpha, beta, vin, vout);
-    case 8: return diffuse_tile_launch<8>(s, g, r0, r1, alpha, beta, vin, vout);
-    case 10: return diffuse_tile_launch<10>(s, g, r0, r1, alpha, beta, vin, vout);
+    case 1: return diffuse_tile_ty<1>(s, g, r0, r1, ty, alpha, beta, vin, vout);
+    case 2: return diffuse_tile_ty<2>(s, g, r0, r1, ty, alpha, beta, vin, vout);
+    case 4: return diffuse_tile_ty<4>(s, g, r0, r1, ty, alpha, beta, vin, vout);
+    case 5: return diffuse_tile_ty<5>(s, g, r0, r1, ty, alpha, beta, vin, vout);
+    case 8: return diffuse_tile_ty<8>(s, g, r0, r1, ty, alpha, beta, vin, vout);
+    case 10: return diffuse_tile_ty<10>(s, g, r0, r1, ty, alpha, beta, vin, vout);
     default: return false;
   }
 }

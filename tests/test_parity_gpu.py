@@ -411,13 +411,15 @@ def test_temporal_blocking_every_phase_at_the_borders(pkg, hip, oracle, k, cols,
                 assert_bit_equal(a[f], b[f], f"{stage}/{f} n={n} k={k} cols={cols}")
 
 
+@pytest.mark.parametrize("ty", [32, 16])
 @pytest.mark.parametrize("k", [1, 2, 4, 5, 8, 10])
-def test_lds_tiles_bit_exact(pkg, hip, oracle, k, monkeypatch):
-    """The small-grid path (fluid_kernels_tile.hip: K sweeps on a 64 x 32 tile held in LDS) gives the
-    bits of the sweep-by-sweep oracle: grids that are not multiples of the tile, tiles cut by every
-    domain border, sweep counts that split into mixed passes, later passes starting from a
+def test_lds_tiles_bit_exact(pkg, hip, oracle, k, ty, monkeypatch):
+    """The small-grid path (fluid_kernels_tile.hip: K sweeps on a 64 x 32 or 64 x 16 tile held in LDS)
+    gives the bits of the sweep-by-sweep oracle: grids that are not multiples of the tile, tiles cut
+    by every domain border, sweep counts that split into mixed passes, later passes starting from a
     non-zero iterate."""
     monkeypatch.setenv("FLUID_TILE", "1")
+    monkeypatch.setenv("FLUID_TILE_TY", str(ty))
     monkeypatch.setenv("FLUID_TB_KJ", str(k))
     monkeypatch.setenv("FLUID_TB_KD", str(k))
     for n, D, J in ((96, 2 * k + 1, 3 * k), (100, k, 2 * k + 3), (31, 3, 7), (257, 10, 40)):
@@ -433,9 +435,11 @@ def test_lds_tiles_bit_exact(pkg, hip, oracle, k, monkeypatch):
                 assert_bit_equal(a[f], b[f], f"{stage}/{f} n={n} k={k}")
 
 
-def test_lds_tiles_whole_steps_and_zero_sweeps(pkg, hip, oracle, monkeypatch):
+@pytest.mark.parametrize("ty", [32, 16])
+def test_lds_tiles_whole_steps_and_zero_sweeps(pkg, hip, oracle, ty, monkeypatch):
     """Whole seeded steps through the tile path, including J = 0 and D = 0."""
     monkeypatch.setenv("FLUID_TILE", "1")
+    monkeypatch.setenv("FLUID_TILE_TY", str(ty))
     for n, D, J in ((128, 10, 40), (200, 0, 5), (64, 3, 0)):
         gpu, ref = pair(pkg, hip, oracle, n, diffusion_iters=D, pressure_iters=J)
         pkg.run_seeded(gpu, 4)

@@ -58,6 +58,29 @@ for i in range(na):
     g.close(); r.close()
 print(f"A done ({na} cases), mismatches so far {bad}", flush=True)
 
+for i in range(na // 2):   # A'': rectangular grids (fluid_params.ny), random tile / pipeline choice
+    nx, ny = int(rng.integers(4, 700)), int(rng.integers(4, 700))
+    if rng.random() < 0.6:
+        nx = max(nx // 4 * 4, 4)
+    D, J = int(rng.integers(0, 13)), int(rng.integers(0, 46))
+    r_ = np.random.default_rng(900 + i)
+    vmax = float(rng.uniform(1, 60))
+    st = (r_.uniform(-vmax, vmax, (ny, nx, 2)).astype(np.float32), r_.uniform(0, 1, (ny, nx, 4)).astype(np.float32),
+          r_.uniform(-1, 1, (ny, nx)).astype(np.float32))
+    os.environ["FLUID_TILE"] = str(int(rng.integers(0, 2)))
+    os.environ["FLUID_TILE_TY"] = str(int(rng.choice([16, 32])))
+    g = pkg.FluidSim(nx, ny=ny, diffusion_iters=D, pressure_iters=J)
+    os.environ.pop("FLUID_TILE"); os.environ.pop("FLUID_TILE_TY")
+    r = pkg.FluidSim(nx, ny=ny, lib=oracle, diffusion_iters=D, pressure_iters=J)
+    load_state(g, pkg, *st)
+    load_state(r, pkg, *st)
+    steps = int(rng.integers(1, 3))
+    g.step(steps)
+    r.step(steps)
+    compare(f"A'' {nx}x{ny} D={D} J={J} steps={steps}", g, r)
+    g.close(); r.close()
+print(f"A'' done ({na // 2} cases), mismatches so far {bad}", flush=True)
+
 for i in range(na // 4):   # A': vorticity confinement on (whole-domain contexts only)
     n = int(rng.integers(4, 300))
     D, J = int(rng.integers(0, 13)), int(rng.integers(0, 30))
@@ -120,7 +143,7 @@ for i in range(nc):
 print(f"C done ({nc} cases), mismatches {bad}", flush=True)
 
 PLAN_ENV = ("FLUID_TB_KJ", "FLUID_TB_KD", "FLUID_TB_CJ", "FLUID_TB_CD", "FLUID_TB_WAVES", "FLUID_TB_MINCHUNK", "FLUID_TILE",
-            "FLUID_INTERIOR_SPLIT", "FLUID_INTERIOR_PIECE_MIN")
+            "FLUID_TILE_TY", "FLUID_INTERIOR_SPLIT", "FLUID_INTERIOR_PIECE_MIN")
 for i in range(nd):
     for k in PLAN_ENV:
         os.environ.pop(k, None)
@@ -128,7 +151,7 @@ for i in range(nd):
            "FLUID_TB_CJ": int(rng.choice([2, 4])), "FLUID_TB_CD": int(rng.choice([2, 4])),
            "FLUID_TB_WAVES": int(rng.choice([1, 7, 64, 500, 2048, 3900, 20000])),
            "FLUID_TB_MINCHUNK": int(rng.integers(1, 5)), "FLUID_TILE": int(rng.integers(0, 2)),
-           "FLUID_INTERIOR_SPLIT": int(rng.integers(1, 9)), "FLUID_INTERIOR_PIECE_MIN": int(rng.choice([1, 5000, 1 << 21]))}
+           "FLUID_TILE_TY": int(rng.choice([16, 32])), "FLUID_INTERIOR_SPLIT": int(rng.integers(1, 9)), "FLUID_INTERIOR_PIECE_MIN": int(rng.choice([1, 5000, 1 << 21]))}
     D, J = int(rng.integers(0, 13)), int(rng.integers(0, 46))
     count = int(rng.integers(1, 5))
     A = int(rng.integers(1, 9))
