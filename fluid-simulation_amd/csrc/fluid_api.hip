@@ -90,6 +90,8 @@ struct fluid_ctx {
   std::map<int, GraphEntry> graphs;
   // temporal-blocking plan (fused path): sweeps per launch, columns per lane, target waves
   int tb_kj = 10, tb_kd = 5, tb_cj = 2, tb_cd = 2, tb_waves = 8192, tb_minchunk = 4;
+  bool tile_div = true;    // tile path: the last diffusion launch also writes the divergence (FLUID_TILE_DIV)
+  bool div_ready = false;  // ... and did, for the projection about to be enqueued
   int tile_ty = 32;   // rows an LDS tile stores (16 on the smallest grids, see fluid_init)
   bool tile = false;  // small grids: LDS-tiled sweeps (fluid_kernels_tile.hip) instead of the register pipeline
   bool nt_stores = false;  // grids far beyond the caches: non-temporal stores in the two streaming kernels
@@ -311,14 +313,20 @@ bool use_tb(const fluid_ctx *c, int cols) {
 
 // simulateDiffusion()  kernel.cu:582-602.  out_m: margin the final iterate must cover; a
 // sweep with `left` sweeps still to come must cover out_m + left.
-void enq_diffuse(fluid_ctx *c, int out_m) {
+// with_div (whole steps of a whole-domain context on the tile path): the launch that finishes the
+// diffusion also writes the divergence of its result, and the first pressure launch reads it
+// (c->div_ready) instead of recomputing it from the velocity for every cell of its tiles.
+void enq_diffuse(fluid_ctx *c, int out_m, bool with_div = false) {
   const double cells = (double)cells_owned(c);
   if (c->tile && !(c->prm.flags & FLUID_FLAG_UNFUSED)) {
     for (int left = c->prm.diffusion_iters; left > 0;) {
       const int k = next_pass(c, left, true);
-      ProfScope p(c, K_DIFFUSE_TILE, 16.0 * k * cells, 16.0 * cells);
+      const bool div = with_div && left == k;  // the last pass
+      ProfScope p(c, K_DIFFUSE_TILE, 16.0 * k * cells + (div ? 12.0 * cells : 0.0), (div ? 20.0 : 16.0) * cells);
       const Range r = widened(c, out_m + left - k);
-      LAUNCH(c, launch_diffuse_tile(c->stream, c->g, r.r0, r.r1, k, c->tile_ty, c->alpha, c->beta, c->vel[c->vin], c->vel[c->vin ^ 1]));
+      LAUNCH(c, launch_diffuse_tile(c->stream, c->g, r.r0, r.r1, k, c->tile_ty, c->alpha, c->beta, c->vel[c->vin],
+                                    c->vel[c->vin ^ 1], div ? c->div : nullptr));
+      if (div) c->div_ready = true;
       c->vin ^= 1;
       left -= k;
     }
@@ -380,7 +388,11 @@ void enq_pressure_group(fluid_ctx *c, int g) {
     bool first = g == 0;
     while (left > 0) {
       const int k = next_pass(c, left, false);
-      if (first) {
+      if (first && c->div_ready) {  // the diffusion launch wrote the divergence: p^0 == 0, 4 + 4 bytes per cell
+        ProfScope p(c, K_JACOBI_TILE, 12.0 * k * cells, 8.0 * cells);
+        const Range r = widened(c, 1 + left - k);
+        LAUNCH(c, launch_jacobi_tile(c->stream, c->g, r.r0, r.r1, k, c->tile_ty, nullptr, c->div, c->prs[c->pin ^ 1]));
+      } else if (first) {
         ProfScope p(c, K_JACOBI_DIV_TILE, 12.0 * cells + 12.0 * k * cells, 16.0 * cells);  // velocity in, divergence and p out
         const Range r = widened(c, div_m >= 0 ? div_m : 1 + left - k);
         LAUNCH(c, launch_jacobi_div_tile(c->stream, c->g, r.r0, r.r1, k, c->tile_ty, c->vel[c->vin], c->div, c->prs[c->pin ^ 1]));
@@ -394,11 +406,14 @@ void enq_pressure_group(fluid_ctx *c, int g) {
       left -= k;
     }
     if (first) {  // J == 0: still the divergence and the pressure clear
-      ProfScope p(c, K_DIVERGENCE, 12.0 * cells);
-      const Range r = widened(c, div_m >= 0 ? div_m : J);
-      launch_divergence(c->stream, c->g, r.r0, r.r1, c->vel[c->vin], c->div);
+      if (!c->div_ready) {
+        ProfScope p(c, K_DIVERGENCE, 12.0 * cells);
+        const Range r = widened(c, div_m >= 0 ? div_m : J);
+        launch_divergence(c->stream, c->g, r.r0, r.r1, c->vel[c->vin], c->div);
+      }
       HIPNOTE(c, hipMemsetAsync(c->prs[c->pin], 0, cells_local(c) * sizeof(float), c->stream));
     }
+    c->div_ready = false;
     return;
   }
   if (g == 0) {
@@ -526,7 +541,8 @@ void enq_velocity_head(fluid_ctx *c) {
   const int glen = c->groups > 1 ? c->jg : c->prm.pressure_iters;
   const int m_diff = glen + 1;  // diffused velocity feeds divergence on glen rows
   enq_advect_velocity(c, m_diff + c->prm.diffusion_iters);
-  enq_diffuse(c, m_diff);
+  // (vorticity confinement changes the velocity between the two stages; slabs keep the separate form)
+  enq_diffuse(c, m_diff, c->tile_div && !c->slab && !(c->prm.flags & FLUID_FLAG_VORTICITY));
   if (c->prm.flags & FLUID_FLAG_VORTICITY) enq_vorticity(c);  // kernel.cu:705
   enq_pressure_group(c, 0);
 }
@@ -745,6 +761,7 @@ int fluid_init(fluid_ctx **out, const fluid_params *p) {
   // J = 40: 57.9 -> 51.5; slower from 768^2 up, where 32-row tiles already give every CU work)
   c->tile_ty = env_int("FLUID_TILE_TY", owned <= 3 * (1ll << 17) ? 16 : 32);
   if (!tile_has_ty(c->tile_ty)) c->tile_ty = 32;
+  c->tile_div = env_int("FLUID_TILE_DIV", 1) != 0;
   if (c->tile) { c->tb_kj = 10; c->tb_kd = 10; }
   else if (owned < (1ll << 23)) { c->tb_kj = 8; c->tb_kd = 10; c->tb_waves = 2048; }
   else if (owned < (1ll << 24)) { c->tb_kj = 8; c->tb_kd = 5; c->tb_waves = 3900; }

@@ -87,8 +87,11 @@ bool launch_jacobi_tile(hipStream_t s, Geom g, int r0, int r1, int k, int ty, co
                         float *pout);
 bool launch_jacobi_div_tile(hipStream_t s, Geom g, int r0, int r1, int k, int ty, const float2 *vel, float *div_out,
                             float *pout);
+// launch_jacobi_tile with pin == nullptr: the first launch of a projection whose divergence is in
+// memory already (p^0 == 0).  launch_diffuse_tile with div_out: also writes the divergence of the
+// field it stores (the last diffusion launch of a whole step).
 bool launch_diffuse_tile(hipStream_t s, Geom g, int r0, int r1, int k, int ty, float alpha, float beta,
-                         const float2 *vin, float2 *vout);
+                         const float2 *vin, float2 *vout, float *div_out = nullptr);
 
 // ---- diagnostics (fluid_kernels_diag.hip) -----------------------------------
 // Maxima (absolute values) and sums over local rows [r0, r1); rows r0-1 and r1 must hold current

@@ -198,7 +198,11 @@ __device__ __forceinline__ bool stored_segment(const Run<K, TY> &rn, int j, int 
 // rules read inward only.  A tile that touches a domain border or rows that are not stored
 // (slab) still moves whole segments and applies the border rules by side (TileMode); only a grid
 // that is not a multiple of four wide takes the element-wise path.
-template <int K, bool WITH_DIV, int TY>
+// SRC: where the first iterate and the divergence come from
+//   0  both from memory (a later launch of a projection)
+//   1  WITH_DIV (below): p^0 == 0, divergence computed from the velocity
+//   2  p^0 == 0, divergence from memory (first launch when the diffusion launch wrote it, k_diffuse_tile)
+template <int K, int SRC, int TY>
 __global__ __launch_bounds__((TileGeom<K, TY>::THREADS)) void k_jacobi_tile(Geom g, int r0, int r1,
                                                                       const float *__restrict__ pin,
                                                                       const float2 *__restrict__ vel,
@@ -206,6 +210,7 @@ __global__ __launch_bounds__((TileGeom<K, TY>::THREADS)) void k_jacobi_tile(Geom
                                                                       float *__restrict__ div_out,
                                                                       float *__restrict__ pout) {
   using G = TileGeom<K, TY>;
+  constexpr bool WITH_DIV = SRC == 1;
   __shared__ __attribute__((aligned(16))) float lds[2 * G::PLANE];
   float *a = lds + 4, *b = lds + G::PLANE + 4;
   const int n = g.n;
@@ -269,13 +274,13 @@ __global__ __launch_bounds__((TileGeom<K, TY>::THREADS)) void k_jacobi_tile(Geom
       }
     } else if (whole) {
       const size_t id = (size_t)rc * n + rn.x;
-      ce[j] = ld4(pin + id);
+      ce[j] = SRC == 2 ? zero : ld4(pin + id);
       dv[j] = ld4(div_in + id);
     } else {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const size_t id = (size_t)rc * n + clampi(rn.x + i, 0, n - 1);
-        ce[j].v[i] = pin[id];
+        ce[j].v[i] = SRC == 2 ? 0.0f : pin[id];
         dv[j].v[i] = div_in[id];
       }
     }
@@ -311,24 +316,29 @@ __global__ __launch_bounds__((TileGeom<K, TY>::THREADS)) void k_jacobi_tile(Geom
   }
 }
 
-// K diffusion sweeps; the two velocity components are two planes.
-template <int K, int TY>
-__global__ __launch_bounds__((TileGeom<K, TY>::THREADS)) void k_diffuse_tile(Geom g, int r0, int r1, float alpha,
-                                                                       float beta,
-                                                                       const float2 *__restrict__ vin,
-                                                                       float2 *__restrict__ vout) {
-  using G = TileGeom<K, TY>;
+// K diffusion sweeps; the two velocity components are two planes.  DIV: the launch that finishes
+// the diffusion also writes the divergence (kernel.cu:265-289) of the field it stores, so that
+// the first pressure launch reads 4 bytes per cell of divergence instead of three rows of
+// velocity for every cell of ITS tile (halo included: 2.2 times the cells).  The divergence of a
+// stored cell needs the final velocity one cell beyond the stored centre, hence a tile with one
+// more ring of halo than sweeps (geometry of K + 1, K sweeps).
+template <int K, int TY, bool DIV>
+__global__ __launch_bounds__((TileGeom<K + (DIV ? 1 : 0), TY>::THREADS)) void k_diffuse_tile(
+    Geom g, int r0, int r1, float alpha, float beta, const float2 *__restrict__ vin, float2 *__restrict__ vout,
+    float *__restrict__ div_out) {
+  constexpr int HALO = K + (DIV ? 1 : 0);
+  using G = TileGeom<HALO, TY>;
   // four planes; dynamic because the deep tiles need more than the 64 KB static LDS limit
   extern __shared__ __attribute__((aligned(16))) float tile_lds[];
   float *au = tile_lds + 4, *aw = au + G::PLANE, *bu = aw + G::PLANE, *bw = bu + G::PLANE;
   const int n = g.n;
   const int x_org = blockIdx.x * TX - G::HX;
-  const int r_org = r0 + blockIdx.y * TY - K;
+  const int r_org = r0 + blockIdx.y * TY - HALO;
   const int y_org = g.ybase + r_org;
   const bool edge = x_org <= 0 || x_org + G::W >= n || y_org <= 0 || y_org + G::H >= g.ny || r_org < 0 ||
                     r_org + G::H > g.L;
   const int mode = (n & 3) ? TILE_CELLS : edge ? TILE_BORDER : TILE_INSIDE;
-  Run<K, TY> rn;
+  Run<HALO, TY> rn;
   rn.locate(x_org, y_org, n, g.ny);
   F4 cu[R], cw[R], none[R];
 #pragma unroll
@@ -360,8 +370,8 @@ __global__ __launch_bounds__((TileGeom<K, TY>::THREADS)) void k_diffuse_tile(Geo
 #pragma unroll 1
   for (int s = 0; s < K; ++s) {
     if (rn.active) {
-      run_sweep<K, TY, DiffuseRule>(au, bu, rn, cu, none, mode, n, g.ny, alpha, beta);
-      run_sweep<K, TY, DiffuseRule>(aw, bw, rn, cw, none, mode, n, g.ny, alpha, beta);
+      run_sweep<HALO, TY, DiffuseRule>(au, bu, rn, cu, none, mode, n, g.ny, alpha, beta);
+      run_sweep<HALO, TY, DiffuseRule>(aw, bw, rn, cw, none, mode, n, g.ny, alpha, beta);
     }
     __syncthreads();
     float *t = au; au = bu; bu = t;
@@ -369,7 +379,7 @@ __global__ __launch_bounds__((TileGeom<K, TY>::THREADS)) void k_diffuse_tile(Geo
   }
 #pragma unroll
   for (int j = 0; j < R; ++j) {
-    if (!stored_segment<K, TY>(rn, j, x_org, y_org, g.ybase + r1, n)) continue;
+    if (!stored_segment<HALO, TY>(rn, j, x_org, y_org, g.ybase + r1, n)) continue;
     const size_t id = (size_t)(rn.y + j - g.ybase) * n + rn.x;
     if (mode != TILE_CELLS) {
       float *q = reinterpret_cast<float *>(vout + id);
@@ -379,6 +389,29 @@ __global__ __launch_bounds__((TileGeom<K, TY>::THREADS)) void k_diffuse_tile(Geo
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         if (rn.x + i < n) vout[id + i] = make_float2(cu[j].v[i], cw[j].v[i]);
+    }
+    if constexpr (DIV) {
+      // the final iterate: this run's cells are in cu / cw, everything around them in the planes
+      // the last sweep wrote (au / aw after the swap); a stored cell is K + 1 or more from the
+      // tile edge, its four neighbours K or more: right after K sweeps
+      const F4 wB = j > 0 ? cw[j - 1] : ld4(aw + rn.cm), wT = j < R - 1 ? cw[j + 1] : ld4(aw + rn.cp);
+      const float uL = au[rn.c0 + j * G::W - 1], uR = au[rn.c0 + j * G::W + 4];
+      F4 d;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float l = i > 0 ? cu[j].v[i - 1] : uL, r = i < 3 ? cu[j].v[i + 1] : uR;
+        const int x = rn.x + i, y = rn.y + j;
+        float v = 0.5f * ((r - l) + (wT.v[i] - wB.v[i]));                       // kernel.cu:282
+        if (x <= 0 || x >= n - 1 || y <= 0 || y >= g.ny - 1) v = 0.0f;         // kernel.cu:287
+        d.v[i] = v;
+      }
+      if (mode != TILE_CELLS) {
+        st4(div_out + id, d);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (rn.x + i < n) div_out[id + i] = d.v[i];
+      }
     }
   }
 }
@@ -397,13 +430,13 @@ bool tile_has_k(int k, bool) {
 }
 bool tile_has_ty(int ty) { return ty == 16 || ty == 32; }
 
-template <int K, bool DIV, int TY>
+template <int K, int DIV, int TY>
 void jacobi_tile_launch(hipStream_t s, Geom g, int r0, int r1, const float *pin, const float2 *vel, const float *div_in,
                         float *div_out, float *pout) {
   k_jacobi_tile<K, DIV, TY><<<tile_grid(g, r0, r1, TY), TileGeom<K, TY>::THREADS, 0, s>>>(g, r0, r1, pin, vel, div_in,
                                                                                           div_out, pout);
 }
-template <int K, bool DIV>
+template <int K, int DIV>
 bool jacobi_tile_ty(hipStream_t s, Geom g, int r0, int r1, int ty, const float *pin, const float2 *vel,
                     const float *div_in, float *div_out, float *pout) {
   if (ty == 16) jacobi_tile_launch<K, DIV, 16>(s, g, r0, r1, pin, vel, div_in, div_out, pout);
@@ -411,7 +444,7 @@ bool jacobi_tile_ty(hipStream_t s, Geom g, int r0, int r1, int ty, const float *
   else return false;
   return true;
 }
-template <bool DIV>
+template <int DIV>
 bool jacobi_tile_k(hipStream_t s, Geom g, int r0, int r1, int k, int ty, const float *pin, const float2 *vel,
                    const float *div_in, float *div_out, float *pout) {
   switch (k) {
@@ -428,51 +461,59 @@ bool jacobi_tile_k(hipStream_t s, Geom g, int r0, int r1, int k, int ty, const f
 bool launch_jacobi_tile(hipStream_t s, Geom g, int r0, int r1, int k, int ty, const float *pin, const float *div_in,
                         float *pout) {
   if (r1 <= r0) return true;
-  return jacobi_tile_k<false>(s, g, r0, r1, k, ty, pin, nullptr, div_in, nullptr, pout);
+  if (!pin) return jacobi_tile_k<2>(s, g, r0, r1, k, ty, nullptr, nullptr, div_in, nullptr, pout);  // p^0 == 0
+  return jacobi_tile_k<0>(s, g, r0, r1, k, ty, pin, nullptr, div_in, nullptr, pout);
 }
 
 bool launch_jacobi_div_tile(hipStream_t s, Geom g, int r0, int r1, int k, int ty, const float2 *vel, float *div_out,
                             float *pout) {
   if (r1 <= r0) return true;
-  return jacobi_tile_k<true>(s, g, r0, r1, k, ty, nullptr, vel, nullptr, div_out, pout);
+  return jacobi_tile_k<1>(s, g, r0, r1, k, ty, nullptr, vel, nullptr, div_out, pout);
 }
 
-template <int K, int TY>
+template <int K, int TY, bool DIV>
 bool diffuse_tile_launch(hipStream_t s, Geom g, int r0, int r1, float alpha, float beta, const float2 *vin,
-                         float2 *vout) {
-  using G = TileGeom<K, TY>;
+                         float2 *vout, float *div_out) {
+  using G = TileGeom<K + (DIV ? 1 : 0), TY>;
   constexpr size_t bytes = 4 * (size_t)G::PLANE * sizeof(float);
   // more than 64 KB of LDS per workgroup is an opt-in, once per kernel AND device (a context on
   // another device, fluid_params.device, has its own copy of the code object)
   static bool raised[64] = {false};
   int dev = 0;
   if (bytes > 64 * 1024 && (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || !raised[dev])) {
-    if (hipFuncSetAttribute((const void *)k_diffuse_tile<K, TY>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute((const void *)k_diffuse_tile<K, TY, DIV>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)bytes) != hipSuccess)
       return false;
     if (dev >= 0 && dev < 64) raised[dev] = true;
   }
-  k_diffuse_tile<K, TY><<<tile_grid(g, r0, r1, TY), G::THREADS, bytes, s>>>(g, r0, r1, alpha, beta, vin, vout);
+  k_diffuse_tile<K, TY, DIV><<<tile_grid(g, r0, r1, TY), G::THREADS, bytes, s>>>(g, r0, r1, alpha, beta, vin, vout,
+                                                                                div_out);
   return true;
 }
 template <int K>
 bool diffuse_tile_ty(hipStream_t s, Geom g, int r0, int r1, int ty, float alpha, float beta, const float2 *vin,
-                     float2 *vout) {
-  if (ty == 16) return diffuse_tile_launch<K, 16>(s, g, r0, r1, alpha, beta, vin, vout);
-  if (ty == 32) return diffuse_tile_launch<K, 32>(s, g, r0, r1, alpha, beta, vin, vout);
+                     float2 *vout, float *div_out) {
+  if (div_out) {
+    if (ty == 16) return diffuse_tile_launch<K, 16, true>(s, g, r0, r1, alpha, beta, vin, vout, div_out);
+    if (ty == 32) return diffuse_tile_launch<K, 32, true>(s, g, r0, r1, alpha, beta, vin, vout, div_out);
+    return false;
+  }
+  if (ty == 16) return diffuse_tile_launch<K, 16, false>(s, g, r0, r1, alpha, beta, vin, vout, nullptr);
+  if (ty == 32) return diffuse_tile_launch<K, 32, false>(s, g, r0, r1, alpha, beta, vin, vout, nullptr);
   return false;
 }
 
+// div_out != nullptr: also write the divergence of the stored field (whole rows [r0, r1))
 bool launch_diffuse_tile(hipStream_t s, Geom g, int r0, int r1, int k, int ty, float alpha, float beta,
-                         const float2 *vin, float2 *vout) {
+                         const float2 *vin, float2 *vout, float *div_out) {
   if (r1 <= r0) return true;
   switch (k) {
-    case 1: return diffuse_tile_ty<1>(s, g, r0, r1, ty, alpha, beta, vin, vout);
-    case 2: return diffuse_tile_ty<2>(s, g, r0, r1, ty, alpha, beta, vin, vout);
-    case 4: return diffuse_tile_ty<4>(s, g, r0, r1, ty, alpha, beta, vin, vout);
-    case 5: return diffuse_tile_ty<5>(s, g, r0, r1, ty, alpha, beta, vin, vout);
-    case 8: return diffuse_tile_ty<8>(s, g, r0, r1, ty, alpha, beta, vin, vout);
-    case 10: return diffuse_tile_ty<10>(s, g, r0, r1, ty, alpha, beta, vin, vout);
+    case 1: return diffuse_tile_ty<1>(s, g, r0, r1, ty, alpha, beta, vin, vout, div_out);
+    case 2: return diffuse_tile_ty<2>(s, g, r0, r1, ty, alpha, beta, vin, vout, div_out);
+    case 4: return diffuse_tile_ty<4>(s, g, r0, r1, ty, alpha, beta, vin, vout, div_out);
+    case 5: return diffuse_tile_ty<5>(s, g, r0, r1, ty, alpha, beta, vin, vout, div_out);
+    case 8: return diffuse_tile_ty<8>(s, g, r0, r1, ty, alpha, beta, vin, vout, div_out);
+    case 10: return diffuse_tile_ty<10>(s, g, r0, r1, ty, alpha, beta, vin, vout, div_out);
     default: return false;
   }
 }
