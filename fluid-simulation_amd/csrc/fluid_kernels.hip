@@ -146,11 +146,13 @@ constexpr int ADV_ROWS_DENS = ADV_RD;  // float4 texels: more rows cost occupanc
   if (x >= g.n) return;
 
 // kernel.cu:114-140
-template <bool NT>
+// ADV_ROWS: rows per thread.  Four on the grids that matter for bandwidth; one on the smallest
+// (up to ~600^2), where a launch is a single wave of workgroups and what counts is how many
+// lanes share the two dependent round trips (512^2, J = 10: 26.4 -> 25.0 us per step).
+template <bool NT, int ADV_ROWS>
 __global__ __launch_bounds__(BX *BY) void k_advect_vel(Geom g, int r0, int r1, Rows second, Valid valid, float dt,
                                                         const float2 *__restrict__ vin,
                                                         float2 *__restrict__ vout, int *flag) {
-  constexpr int ADV_ROWS = ADV_ROWS_VEL;
   if (blockIdx.z) { r0 = second.r0; r1 = second.r1; }  // two row ranges in one launch (slab edges)
   ADVECT_PROLOGUE
   float2 v[ADV_ROWS];
@@ -448,18 +450,23 @@ void launch_advect_vel(hipStream_t s, Geom g, int r0, int r1, int vlo, int vhi, 
   if (r1 <= r0) { r0 = r0b; r1 = r1b; r0b = r1b = 0; }
   if (r1 <= r0) return;
   const bool two = r1b > r0b;
-  dim3 grid = grid_adv(g, r0, r1, ADV_ROWS_VEL);
+  const bool small = (long long)g.n * g.L <= 3 * (1ll << 17);  // see k_advect_vel
+  const int rows_per_thread = small ? 1 : ADV_ROWS_VEL;
+  dim3 grid = grid_adv(g, r0, r1, rows_per_thread);
   if (two) {
-    const dim3 gb = grid_adv(g, r0b, r1b, ADV_ROWS_VEL);
+    const dim3 gb = grid_adv(g, r0b, r1b, rows_per_thread);
     grid.y = grid.y > gb.y ? grid.y : gb.y;
     grid.z = 2;
   }
-  if (nt)
-    hipLaunchKernelGGL(k_advect_vel<true>, grid, kBlock, 0, s, g, r0, r1, Rows{r0b, r1b}, Valid{vlo, vhi}, dt, vin,
-                       vout, flag);
+  if (small)
+    hipLaunchKernelGGL((k_advect_vel<false, 1>), grid, kBlock, 0, s, g, r0, r1, Rows{r0b, r1b}, Valid{vlo, vhi}, dt,
+                       vin, vout, flag);
+  else if (nt)
+    hipLaunchKernelGGL((k_advect_vel<true, ADV_ROWS_VEL>), grid, kBlock, 0, s, g, r0, r1, Rows{r0b, r1b},
+                       Valid{vlo, vhi}, dt, vin, vout, flag);
   else
-    hipLaunchKernelGGL(k_advect_vel<false>, grid, kBlock, 0, s, g, r0, r1, Rows{r0b, r1b}, Valid{vlo, vhi}, dt, vin,
-                       vout, flag);
+    hipLaunchKernelGGL((k_advect_vel<false, ADV_ROWS_VEL>), grid, kBlock, 0, s, g, r0, r1, Rows{r0b, r1b},
+                       Valid{vlo, vhi}, dt, vin, vout, flag);
 }
 void launch_diffuse(hipStream_t s, Geom g, int r0, int r1, float alpha, float beta,
                     const float2 *vin, float2 *vout) {
