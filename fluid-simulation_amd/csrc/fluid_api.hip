@@ -90,6 +90,7 @@ struct fluid_ctx {
   std::map<int, GraphEntry> graphs;
   // temporal-blocking plan (fused path): sweeps per launch, columns per lane, target waves
   int tb_kj = 10, tb_kd = 5, tb_cj = 2, tb_cd = 2, tb_waves = 8192, tb_minchunk = 4;
+  int tb_waves_d = 0;  // target waves of the diffusion launches (0 = tb_waves): they hold more registers, so fewer are resident
   bool tile_div = true;    // tile path: the last diffusion launch also writes the divergence (FLUID_TILE_DIV)
   bool div_ready = false;  // ... and did, for the projection about to be enqueued
   int tile_ty = 32;   // rows an LDS tile stores (16 on the smallest grids, see fluid_init)
@@ -297,11 +298,12 @@ void fill_pass_tables(fluid_ctx *c) {
 }
 
 // Rows per wave so that the launch has about tb_waves waves.
-int tb_chunk(const fluid_ctx *c, int k, int cols, int rows) {
+int tb_chunk(const fluid_ctx *c, int k, int cols, int rows, int waves = 0) {
+  if (waves <= 0) waves = c->tb_waves;
   const int hx = (k + cols - 1) / cols * cols;
   const int vw = 64 * cols - 2 * hx;
   const int strips = (c->g.n + vw - 1) / vw;
-  const int chunks = c->tb_waves / strips > 1 ? c->tb_waves / strips : 1;
+  const int chunks = waves / strips > 1 ? waves / strips : 1;
   int chunk = (rows + chunks - 1) / chunks;
   if (chunk < c->tb_minchunk * k) chunk = c->tb_minchunk * k;  // bound the y-halo recompute (2k rows per chunk)
   return chunk;
@@ -338,7 +340,7 @@ void enq_diffuse(fluid_ctx *c, int out_m, bool with_div = false) {
       ProfScope p(c, K_DIFFUSE_TB, 16.0 * k * cells, 16.0 * cells);
       const Range r = widened(c, out_m + left - k);
       LAUNCH(c, launch_diffuse_tb(c->stream, c->g, r.r0, r.r1, k, c->tb_cd,
-                               tb_chunk(c, k, c->tb_cd, r.r1 - r.r0), c->alpha, c->beta, c->vel[c->vin],
+                               tb_chunk(c, k, c->tb_cd, r.r1 - r.r0, c->tb_waves_d), c->alpha, c->beta, c->vel[c->vin],
                                c->vel[c->vin ^ 1], c->dump));
       c->vin ^= 1;
       left -= k;
@@ -764,8 +766,10 @@ int fluid_init(fluid_ctx **out, const fluid_params *p) {
   c->tile_div = env_int("FLUID_TILE_DIV", 1) != 0;
   if (c->tile) { c->tb_kj = 10; c->tb_kd = 10; }
   else if (owned < (1ll << 23)) { c->tb_kj = 8; c->tb_kd = 10; c->tb_waves = 2048; }
-  else if (owned < (1ll << 24)) { c->tb_kj = 8; c->tb_kd = 5; c->tb_waves = 3900; }
-  else if (owned < (1ll << 25)) { c->tb_kj = 10; c->tb_kd = 10; c->tb_waves = 3900; }
+  // (the diffusion pipeline holds 160 VGPRs, three waves per SIMD: its resident round is 3072 waves, not
+  //  4096; just under it, 4096^2: 105 -> 95 us per diffusion launch, tools/waves_d_sweep.py)
+  else if (owned < (1ll << 24)) { c->tb_kj = 8; c->tb_kd = 5; c->tb_waves = 3900; c->tb_waves_d = 2900; }
+  else if (owned < (1ll << 25)) { c->tb_kj = 10; c->tb_kd = 10; c->tb_waves = 3900; c->tb_waves_d = 2900; }
   else if (owned < (1ll << 26)) { c->tb_kj = 14; c->tb_kd = 10; c->tb_waves = prm.n >= 12288 ? 3072 : 6100; }
   else if (owned <= (1ll << 27)) { c->tb_kj = 14; c->tb_kd = 10; c->tb_waves = 6100; }
   else { c->tb_kj = 14; c->tb_kd = 10; c->tb_waves = 16384; }
@@ -784,6 +788,7 @@ int fluid_init(fluid_ctx **out, const fluid_params *p) {
   c->tb_cj = env_int("FLUID_TB_CJ", c->tb_cj);
   c->tb_cd = env_int("FLUID_TB_CD", c->tb_cd);
   c->tb_waves = env_int("FLUID_TB_WAVES", c->tb_waves);
+  c->tb_waves_d = env_int("FLUID_TB_WAVES_D", c->tb_waves_d);
   c->tb_minchunk = env_int("FLUID_TB_MINCHUNK", c->tb_minchunk);
   fill_pass_tables(c);
   c->alpha = 1.0f / (prm.viscosity * prm.dt);  // kernel.cu:182, fp32 at run time
