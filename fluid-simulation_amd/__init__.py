@@ -14,7 +14,7 @@ from .capi import (FluidLib, FluidSim, FluidError, FluidParams, FluidDiag, Kerne
                    FIELD_VORTICITY, FLAG_VORTICITY, FLAG_NO_GRAPH, FLAG_UNFUSED, ABI_SYMBOLS, PART_VELOCITY, PART_DENSITY,
                    PART_VELOCITY_HEAD, PART_PRESSURE_GROUP, PART_VELOCITY_TAIL,
                    PART_TAIL_DENSITY_EDGES, PART_TAIL_DENSITY_INTERIOR, PART_ADVECT_INTERIOR)
-from . import viz, replay as replay_mod
+from . import capi, viz, replay as replay_mod
 from .replay import replay, parse_events
 from .splats import SplatStream, COLOR_PRESETS, alg_bytes_per_cell, run_seeded, DEFAULT_SEED
 
@@ -25,5 +25,5 @@ __all__ = [
     "FLAG_VORTICITY", "FLAG_NO_GRAPH", "FLAG_UNFUSED", "ABI_SYMBOLS", "PART_VELOCITY", "PART_DENSITY",
     "PART_VELOCITY_HEAD", "PART_PRESSURE_GROUP", "PART_VELOCITY_TAIL",
     "PART_TAIL_DENSITY_EDGES", "PART_TAIL_DENSITY_INTERIOR", "PART_ADVECT_INTERIOR",
-    "viz", "replay", "parse_events", "SplatStream", "COLOR_PRESETS", "alg_bytes_per_cell", "run_seeded", "DEFAULT_SEED",
+    "capi", "viz", "replay", "parse_events", "SplatStream", "COLOR_PRESETS", "alg_bytes_per_cell", "run_seeded", "DEFAULT_SEED",
 ]

@@ -52,6 +52,7 @@ struct GraphEntry {
   hipGraph_t graph = nullptr;
   int next_state = 0;
   long long exchanges = 0, bytes = 0;  // halo exchanges / bytes sent per launch (slab graphs with a transport)
+  int halo_after = 0;                  // halo_state the captured steps leave behind
 };
 
 struct ProfRec {
@@ -1078,6 +1079,7 @@ int fluid_time_steps(fluid_ctx *c, int nsteps, float *ms_out) {
 int fluid_profile_steps(fluid_ctx *c, int nsteps, fluid_kernel_stat *stats, int max_stats,
                         int *count) {
   if (!c || nsteps < 0 || !stats || !count || max_stats <= 0) return FLUID_E_INVALID;
+  if (c->slab && c->has_comm) return FLUID_E_UNSUPPORTED;  // per-launch events on one stream; the step runs on two
   if (c->slab && nsteps > 1) return FLUID_E_UNSUPPORTED;
   if (c->groups > 1 && nsteps > 0) return FLUID_E_UNSUPPORTED;
   HIPCHK(c, hipSetDevice(c->prm.device));
@@ -1356,6 +1358,7 @@ static int run_comm_steps(fluid_ctx *c, int nsteps) {
       if (!rc && c->halo_state == HALO_POSTED) rc = wait_exchange(c);  // joins comm_stream back into the capture
       const hipError_t e = hipStreamEndCapture(c->stream, &ge.graph);
       ge.next_state = state_of(c);
+      ge.halo_after = c->halo_state;  // joined (split last kernel) or none (FLUID_FLAG_UNFUSED: no exchange posted yet)
       ge.exchanges = c->comm_exchanges - ex0;
       ge.bytes = c->comm_bytes - by0;
       set_state(c, state0);
@@ -1381,7 +1384,7 @@ static int run_comm_steps(fluid_ctx *c, int nsteps) {
     HIPCHK(c, hipGraphLaunch(it->second.exec, c->stream));
     set_state(c, it->second.next_state);
     c->advect_early = false;
-    c->halo_state = HALO_JOINED;
+    c->halo_state = it->second.halo_after;
     c->comm_exchanges += it->second.exchanges;
     c->comm_bytes += it->second.bytes;
     s += batch;

@@ -375,6 +375,48 @@ def test_library_driven_exchange_multiprocess_on_one_gpu(world, n, J, groups):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,J,groups,flags", [(512, 10, 0, 0), (2048, 12, 0, 0), (384, 30, 3, 0), (512, 10, 0, 4)])
+def test_library_step_as_graphs_equals_direct_enqueue(pkg, hip, n, J, groups, flags, monkeypatch):
+    """The capture logic of the library-driven slab step — compute stream and comm stream forked and
+    joined by events inside one hipGraph, batches of 16 + 4 + 1 steps, the state machine of the
+    halos across add_source — with a capturable transport whose calls do nothing (a middle slab
+    whose neighbours never answer: its halo rows keep what the cone recompute left, the same in
+    both runs).  Graph replay must give the bits of direct enqueueing, report graph mode, and
+    have built its graphs; a non-capturable transport must fall back to direct enqueueing."""
+    def run(graph, capturable=1):
+        monkeypatch.setenv("FLUID_COMM_GRAPH", str(graph))
+        sim = pkg.FluidSim(n, lib=hip, slab_rank=1, slab_count=4, pressure_iters=J, halo_rows=2, pressure_groups=groups,
+                           flags=flags)
+        cbs = (pkg.capi.TRANSPORT_GROUP_START(lambda u: 0), pkg.capi.TRANSPORT_SEND(lambda u, p, b, r, st: 0),
+               pkg.capi.TRANSPORT_RECV(lambda u, p, b, r, st: 0), pkg.capi.TRANSPORT_GROUP_END(lambda u, st: 0))
+        tr = pkg.FluidTransport(None, *cbs, capturable)
+        sim.comm_attach(tr)
+        ss = pkg.SplatStream()
+        sim.add_source(*ss.splat())
+        sim.step(1)
+        sim.step(5)
+        sim.add_source(*ss.splat())     # halos invalid: the next call exchanges eagerly first
+        sim.step(21)                    # 16 + 4 + 1
+        sim.sync()
+        out = [sim.read(f) for f in (pkg.FIELD_VELOCITY, pkg.FIELD_DENSITY, pkg.FIELD_PRESSURE)]
+        info = sim.comm_info()
+        sim.comm_detach()
+        sim.close()
+        return out, info, cbs
+    a, ia, _ = run(1)
+    b, ib, _ = run(0)
+    c, ic, _ = run(1, capturable=0)
+    assert ia["graph"] and ia["graphs_built"] >= 3 and ia["note"] == "", ia
+    assert not ib["graph"] and ib["graphs_built"] == 0, ib
+    assert not ic["graph"] and ic["graphs_built"] == 0, ic
+    assert ia["exchanges"] == ib["exchanges"] == ic["exchanges"] and ia["bytes_sent"] == ib["bytes_sent"] > 0
+    for x, y, z, f in zip(a, b, c, ("velocity", "density", "pressure")):
+        assert float(np.abs(x).max()) > 0
+        assert_bit_equal(x, y, f"{f}: graphs vs direct")
+        assert_bit_equal(z, y, f"{f}: non-capturable vs direct")
+
+
+@pytest.mark.gpu
 def test_rccl_binding_on_one_gpu(pkg, hip):
     """The RCCL leg of the transport on the one GPU a test box has: a one-rank communicator sends
     to itself through the calls the slab step makes (ncclGroupStart / ncclSend / ncclRecv /
