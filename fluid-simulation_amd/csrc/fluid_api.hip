@@ -91,6 +91,7 @@ struct fluid_ctx {
   std::map<int, GraphEntry> graphs;
   // temporal-blocking plan (fused path): sweeps per launch, columns per lane, target waves
   int tb_kj = 10, tb_kd = 5, tb_cj = 2, tb_cd = 2, tb_waves = 8192, tb_minchunk = 4;
+  float tb_rounds = 0.f;  // > 0: size the temporally blocked launches to this many resident rounds of workgroups (tb_chunk)
   int tb_waves_d = 0;  // target waves of the diffusion launches (0 = tb_waves): they hold more registers, so fewer are resident
   bool tile_div = true;    // tile path: the last diffusion launch also writes the divergence (FLUID_TILE_DIV)
   bool div_ready = false;  // ... and did, for the projection about to be enqueued
@@ -296,15 +297,32 @@ void fill_pass_tables(fluid_ctx *c) {
   c->pass_j.assign(c->prm.pressure_iters + 1, 1);
   for (int l = 1; l <= c->prm.diffusion_iters; ++l) c->pass_d[l] = plan_pass(l, c->tb_kd, c->tile ? 0 : c->tb_cd, true, c->tile);
   for (int l = 1; l <= c->prm.pressure_iters; ++l) c->pass_j[l] = plan_pass(l, c->tb_kj, c->tile ? 0 : c->tb_cj, false, c->tile);
+  if (!c->tile && c->tb_rounds > 0.f) {  // ask the runtime for the occupancies now, not while a step is enqueued or captured
+    for (int k : c->pass_d) (void)tb_resident_blocks(2, k, c->tb_cd);
+    for (int k : c->pass_j) { (void)tb_resident_blocks(0, k, c->tb_cj); (void)tb_resident_blocks(1, k, c->tb_cj); }
+  }
 }
 
-// Rows per wave so that the launch has about tb_waves waves.
-int tb_chunk(const fluid_ctx *c, int k, int cols, int rows, int waves = 0) {
-  if (waves <= 0) waves = c->tb_waves;
-  const int hx = (k + cols - 1) / cols * cols;
-  const int vw = 64 * cols - 2 * hx;
-  const int strips = (c->g.n + vw - 1) / vw;
-  const int chunks = waves / strips > 1 ? waves / strips : 1;
+// Rows per wave (chunk) of a temporally blocked launch of `kind` (0 pressure, 1 divergence +
+// pressure, 2 diffusion).  With tb_rounds > 0 the launch is sized to that many RESIDENT ROUNDS of
+// workgroups: resident = what the runtime says fits the device at this kernel's register count, a
+// workgroup is four strips wide, so chunks = floor(rounds * resident / workgroups per chunk-row) —
+// a launch a few workgroups over a round pays a whole extra round for them (8192^2, J = 200:
+// 3034 waves asked for = 37 x 21 workgroups = 777 > 768 resident: 5.26 ms against 4.45 ms at 35 x 21).
+// Otherwise about tb_waves waves (the largest grids: many rounds, shorter chunks even out the end).
+int tb_chunk(const fluid_ctx *c, int kind, int k, int cols, int rows) {
+  int chunks = 0;
+  const int resident = c->tb_rounds > 0.f ? tb_resident_blocks(kind, k, cols) : 0;
+  if (resident > 0) {
+    chunks = (int)(c->tb_rounds * resident) / tb_blocks_per_row(c->g.n, k, cols);
+  } else {
+    const int waves = kind == 2 && c->tb_waves_d > 0 ? c->tb_waves_d : c->tb_waves;
+    const int hx = (k + cols - 1) / cols * cols;
+    const int vw = 64 * cols - 2 * hx;
+    const int strips = (c->g.n + vw - 1) / vw;
+    chunks = waves / strips;
+  }
+  if (chunks < 1) chunks = 1;
   int chunk = (rows + chunks - 1) / chunks;
   if (chunk < c->tb_minchunk * k) chunk = c->tb_minchunk * k;  // bound the y-halo recompute (2k rows per chunk)
   return chunk;
@@ -341,7 +359,7 @@ void enq_diffuse(fluid_ctx *c, int out_m, bool with_div = false) {
       ProfScope p(c, K_DIFFUSE_TB, 16.0 * k * cells, 16.0 * cells);
       const Range r = widened(c, out_m + left - k);
       LAUNCH(c, launch_diffuse_tb(c->stream, c->g, r.r0, r.r1, k, c->tb_cd,
-                               tb_chunk(c, k, c->tb_cd, r.r1 - r.r0, c->tb_waves_d), c->alpha, c->beta, c->vel[c->vin],
+                               tb_chunk(c, 2, k, c->tb_cd, r.r1 - r.r0), c->alpha, c->beta, c->vel[c->vin],
                                c->vel[c->vin ^ 1], c->dump));
       c->vin ^= 1;
       left -= k;
@@ -427,7 +445,7 @@ void enq_pressure_group(fluid_ctx *c, int g) {
       const int k = next_pass(c, left, false);
       ProfScope p(c, K_JACOBI_DIV_TB, 12.0 * cells + 12.0 * k * cells, 16.0 * cells);  // velocity in, divergence and p out
       const Range r = widened(c, div_m >= 0 ? div_m : 1 + left - k);
-      LAUNCH(c, launch_jacobi_div_tb(c->stream, c->g, r.r0, r.r1, k, c->tb_cj, tb_chunk(c, k, c->tb_cj, r.r1 - r.r0),
+      LAUNCH(c, launch_jacobi_div_tb(c->stream, c->g, r.r0, r.r1, k, c->tb_cj, tb_chunk(c, 1, k, c->tb_cj, r.r1 - r.r0),
                                   c->vel[c->vin], c->div, c->prs[c->pin ^ 1], c->dump));
       c->pin ^= 1;
       left -= k;
@@ -447,7 +465,7 @@ void enq_pressure_group(fluid_ctx *c, int g) {
       const int k = next_pass(c, left, false);
       ProfScope p(c, K_JACOBI_TB, 12.0 * k * cells, 12.0 * cells);
       const Range r = widened(c, 1 + left - k);
-      LAUNCH(c, launch_jacobi_tb(c->stream, c->g, r.r0, r.r1, k, c->tb_cj, tb_chunk(c, k, c->tb_cj, r.r1 - r.r0),
+      LAUNCH(c, launch_jacobi_tb(c->stream, c->g, r.r0, r.r1, k, c->tb_cj, tb_chunk(c, 0, k, c->tb_cj, r.r1 - r.r0),
                               c->prs[c->pin], c->div, c->prs[c->pin ^ 1], c->dump));
       c->pin ^= 1;
       left -= k;
@@ -748,14 +766,12 @@ int fluid_init(fluid_ctx **out, const fluid_params *p) {
   //   <= 2^20 (up to 1024^2): launch/latency bound -> LDS tiles (fluid_kernels_tile.hip), 10 / 10
   //           sweeps per launch; one resident round of 64 x 32 tiles ends at 1024^2 (1088^2: 0.131 ms
   //           against 0.123 ms for the pipeline)
-  //   < 2^23  (2048^2)       : 8 / 10 sweeps, 2048 waves (0.257 -> 0.201 ms against 8 / 5 sweeps, 8192 waves)
-  //   < 2^24  (a slab of 8 of 8192^2)  : 8 / 5 sweeps, one resident round of waves
-  //   < 2^25  (4096^2, a slab of 4 of 8192^2): 10 / 10 sweeps, just under one resident round
-  //           (4 waves per SIMD x 1024 SIMDs; a few blocks over cost a second round)
-  //   < 2^26  (a slab of 8 of 16384^2) : 14 / 10 sweeps, one round at 3 waves per SIMD when the
-  //           strips alone fill it (wide grids), two rounds otherwise
-  //   <= 2^27 (8192^2, slabs of 4 or 2 of 16384^2): 14 / 10 sweeps, two rounds
-  //   above   (16384^2)      : 14 / 10 sweeps, 16384 waves (shorter chunks even out the tail)
+  //   < 2^24  (2048^2, 3072^2, a slab of 8 of 8192^2): 8 sweeps per pressure launch, 10 / 5 per diffusion
+  //           launch, 2048 waves: half a resident round (more waves: shorter chunks, more halo rows redone)
+  //   < 2^25  (4096^2, a slab of 4 of 8192^2): 10 / 10 sweeps, ONE resident round of workgroups
+  //   <= 2^26 (6144^2, 8192^2, slabs of 8 and 4 of 16384^2): 14 / 10 sweeps, ONE resident round
+  //   <= 2^27 (a slab of 2 of 16384^2): 14 / 10 sweeps, 6100 waves (two rounds)
+  //   above   (12288^2, 16384^2): 14 / 10 sweeps, 16384 waves (shorter chunks even out the tail)
   const long long owned = (long long)prm.n * si.rows;
   c->tile = env_int("FLUID_TILE", owned <= (1ll << 20) ? 1 : 0) != 0;
   c->tb_minchunk = 1;
@@ -767,11 +783,15 @@ int fluid_init(fluid_ctx **out, const fluid_params *p) {
   c->tile_div = env_int("FLUID_TILE_DIV", 1) != 0;
   if (c->tile) { c->tb_kj = 10; c->tb_kd = 10; }
   else if (owned < (1ll << 23)) { c->tb_kj = 8; c->tb_kd = 10; c->tb_waves = 2048; }
-  // (the diffusion pipeline holds 160 VGPRs, three waves per SIMD: its resident round is 3072 waves, not
-  //  4096; just under it, 4096^2: 105 -> 95 us per diffusion launch, tools/waves_d_sweep.py)
-  else if (owned < (1ll << 24)) { c->tb_kj = 8; c->tb_kd = 5; c->tb_waves = 3900; c->tb_waves_d = 2900; }
-  else if (owned < (1ll << 25)) { c->tb_kj = 10; c->tb_kd = 10; c->tb_waves = 3900; c->tb_waves_d = 2900; }
-  else if (owned < (1ll << 26)) { c->tb_kj = 14; c->tb_kd = 10; c->tb_waves = prm.n >= 12288 ? 3072 : 6100; }
+  // From 2^24 to 2^26 owned cells (4096^2 ... 8192^2, slabs of 8 and 4 of 16384^2) a launch is sized to
+  // exactly ONE resident round of workgroups at its own kernel's occupancy (tb_chunk: 4 waves per SIMD
+  // for the 10-sweep pressure kernel, 3 for the 13/14-sweep ones and the diffusion), measured against the
+  // wave targets used before (tools/waves_sweep2.py): 6144^2 1.197 -> 1.085 ms, 8192^2 1.903 -> 1.826,
+  // 8192^2 J=200 4.83 -> 4.43, 4096^2 and the slabs of 16384^2 within 1 %.  Smaller grids do better
+  // under a round (2048 waves), larger ones with several (shorter chunks even out the end).
+  else if (owned < (1ll << 24)) { c->tb_kj = 8; c->tb_kd = 5; c->tb_waves = 2048; c->tb_waves_d = 2900; }  // (3900 before: 3072^2 0.353 -> 0.339 ms, slab of 8 of 8192^2 J=200 1.07 -> 1.01)
+  else if (owned < (1ll << 25)) { c->tb_kj = 10; c->tb_kd = 10; c->tb_waves = 3900; c->tb_waves_d = 2900; c->tb_rounds = 1.f; }
+  else if (owned <= (1ll << 26)) { c->tb_kj = 14; c->tb_kd = 10; c->tb_waves = prm.n >= 12288 ? 3072 : 6100; c->tb_rounds = 1.f; }
   else if (owned <= (1ll << 27)) { c->tb_kj = 14; c->tb_kd = 10; c->tb_waves = 6100; }
   else { c->tb_kj = 14; c->tb_kd = 10; c->tb_waves = 16384; }
   // non-temporal stores in the two streaming kernels (fluid_kernels.hip): measured break-even at
@@ -790,6 +810,8 @@ int fluid_init(fluid_ctx **out, const fluid_params *p) {
   c->tb_cd = env_int("FLUID_TB_CD", c->tb_cd);
   c->tb_waves = env_int("FLUID_TB_WAVES", c->tb_waves);
   c->tb_waves_d = env_int("FLUID_TB_WAVES_D", c->tb_waves_d);
+  if (env_int("FLUID_TB_WAVES", 0) > 0) c->tb_rounds = 0.f;  // an explicit wave target wins over the table's rounds
+  c->tb_rounds = env_int("FLUID_TB_ROUNDS_PCT", (int)(c->tb_rounds * 100.f + 0.5f)) / 100.f;
   c->tb_minchunk = env_int("FLUID_TB_MINCHUNK", c->tb_minchunk);
   fill_pass_tables(c);
   c->alpha = 1.0f / (prm.viscosity * prm.dt);  // kernel.cu:182, fp32 at run time

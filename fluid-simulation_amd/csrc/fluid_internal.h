@@ -69,6 +69,8 @@ void launch_add_vorticity(hipStream_t s, Geom g, int r0, int r1, float dt, const
 // the straight kernels): n % cols != 0 or k not instantiated.  dump: one row of
 // n * 16 bytes of device memory that receives the rows a wave computes but must not store.
 bool tb_supported(int n, int cols);
+int tb_resident_blocks(int kind, int k, int cols);  // kind: 0 pressure, 1 divergence + pressure, 2 diffusion
+int tb_blocks_per_row(int n, int k, int cols);
 bool tb_has_k(int k, int cols, bool float2_field);
 bool launch_jacobi_tb(hipStream_t s, Geom g, int r0, int r1, int k, int cols, int chunk,
                       const float *pin, const float *div, float *pout, void *dump);

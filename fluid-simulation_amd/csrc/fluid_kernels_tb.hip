@@ -714,6 +714,24 @@ void diffuse_tb_launch(hipStream_t s, Geom g, int r0, int r1, int chunk, float a
                                                                 vout, (float2 *)dump);
 }
 
+// Workgroups of one kernel that are resident on the whole device at once (occupancy from the
+// runtime: registers decide it — 108-112 VGPRs: 4 waves per SIMD, 132-160: 3).
+template <class KernelT>
+void resident_blocks_of(KernelT kernel, int *out) {
+  int per_cu = 0, dev = 0, cus = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, WAVE * WAVES_PER_BLOCK, 0) != hipSuccess ||
+      hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+    (void)hipGetLastError();
+    *out = 0;
+    return;
+  }
+  *out = per_cu * cus;
+}
+template <int K, int C> void jacobi_tb_occ(int *out) { resident_blocks_of(k_jacobi_tb<K, C>, out); }
+template <int K, int C> void jacobi_div_tb_occ(int *out) { resident_blocks_of(k_jacobi_div_tb<K, C>, out); }
+template <int K, int C> void diffuse_tb_occ(int *out) { resident_blocks_of(k_diffuse_tb<K, C>, out); }
+
 }  // namespace
 
 // Instantiated sweep counts.  Four columns per lane stop at 5 sweeps, two columns at 10
@@ -780,4 +798,42 @@ bool launch_diffuse_tb(hipStream_t s, Geom g, int r0, int r1, int k, int cols, i
   if (cols == 4) TB_DISPATCH_K4(diffuse_tb_launch, s, g, r0, r1, chunk, alpha, beta, vin, vout, dump)
   TB_DISPATCH_K2(diffuse_tb_launch, s, g, r0, r1, chunk, alpha, beta, vin, vout, dump)
   return false;
+}
+
+// Resident workgroups (4 waves each) of the k-sweep kernel of `kind` (0 pressure, 1 divergence +
+// pressure, 2 diffusion) on the current device; 0 if unknown.  Asked once per kernel.
+namespace {
+bool occ_dispatch(int kind, int k, int cols, int *out) {
+  if (kind == 2) {
+    if (cols == 4) TB_DISPATCH_K4(diffuse_tb_occ, out)
+    TB_DISPATCH_K2(diffuse_tb_occ, out)
+    return false;
+  }
+  if (kind == 1) {
+    if (cols == 4) TB_DISPATCH_K4(jacobi_div_tb_occ, out)
+    TB_DISPATCH_K2(jacobi_div_tb_occ, out)
+    TB_DISPATCH_K2_DEEP(jacobi_div_tb_occ, out)
+    return false;
+  }
+  if (cols == 4) TB_DISPATCH_K4(jacobi_tb_occ, out)
+  TB_DISPATCH_K2(jacobi_tb_occ, out)
+  TB_DISPATCH_K2_DEEP(jacobi_tb_occ, out)
+  return false;
+}
+}  // namespace
+int tb_resident_blocks(int kind, int k, int cols) {
+  static int cache[3][16][5];  // 0 = not asked yet, -1 = unknown
+  if (kind < 0 || kind > 2 || k < 1 || k > 15 || cols < 1 || cols > 4) return 0;
+  int &slot = cache[kind][k][cols];
+  if (slot == 0) {
+    int v = 0;
+    slot = occ_dispatch(kind, k, cols, &v) && v > 0 ? v : -1;
+  }
+  return slot > 0 ? slot : 0;
+}
+// blocks one chunk-row of the launch has (a workgroup is WAVES_PER_BLOCK strips wide)
+int tb_blocks_per_row(int n, int k, int cols) {
+  const int hx = (k + cols - 1) / cols * cols, vw = WAVE * cols - 2 * hx;
+  const int strips = (n + vw - 1) / vw;
+  return (strips + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
 }
