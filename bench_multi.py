@@ -42,6 +42,7 @@ def supervise_rank(argv):
     attempt find each other on MASTER_PORT + 1 + attempt."""
     import signal
     import subprocess
+    import threading
     rank = os.environ.get("RANK", "0")
     modes = os.environ.get("FLUID_BENCH_MODES", default_modes()).split(",")
     base_port = int(os.environ.get("MASTER_PORT", "29500"))
@@ -60,15 +61,34 @@ def supervise_rank(argv):
                    FLUID_BENCH_RANK_TIMEOUT=str(limit))
         env.pop("TORCHELASTIC_USE_AGENT_STORE", None)   # rank 0's child hosts the store of its attempt
         p = subprocess.Popen([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "bench.py")]
-                             + list(argv), env=env)   # same session: whoever ends this rank's session ends the child too
+                             + list(argv), env=env, stdout=subprocess.PIPE,
+                             text=True)   # same session: whoever ends this rank's session ends the child too
         child[0] = p
+        # The job's stdout is ONE JSON line.  Libraries write there too (gloo announces its
+        # connections on stdout), so the child's stdout is read here: the JSON line is held until
+        # the attempt has ended well, everything else goes to stderr.
+        result = []
+
+        def relay(pipe=p.stdout, result=result):
+            for line in pipe:
+                if line.lstrip().startswith("{"):
+                    result.append(line)
+                else:
+                    sys.stderr.write(line)
+                    sys.stderr.flush()
+        reader = threading.Thread(target=relay, daemon=True)
+        reader.start()
         try:
             rc = p.wait(timeout=rendezvous_wait(attempt, limit) + limit + 60)
         except subprocess.TimeoutExpired:
             p.kill()   # exactly the child started above
             p.wait()
             rc = 124
+        reader.join(timeout=10)
         if rc == 0:
+            for line in result:
+                sys.stdout.write(line)
+            sys.stdout.flush()
             return 0
         print(f"bench.py rank {rank}: attempt {attempt} (modes {','.join(modes[attempt:])}) ended with {rc}",
               file=sys.stderr, flush=True)

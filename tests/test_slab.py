@@ -498,8 +498,8 @@ def test_bench_starts_its_own_ranks():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "1024_J40",
                           "--steps", "3", "--warmup", "1"], env=env, capture_output=True, text=True, timeout=400)
     assert out.returncode == 0, out.stderr[-3000:]
-    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout[-2000:]   # stdout is the JSON line and nothing else (gloo's chatter goes to stderr)
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["overlap_matches_plain_exchange"] is True
     assert rec["value"] > 0 and rec["unit"] == "GCUPS"
