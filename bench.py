@@ -48,9 +48,9 @@ def seeded_warm_state(pkg, sim, nsplats=4):
         sim.add_source(*ss.splat())
 
 
-def measure_single(pkg, n, D, J, steps, warmup, flags=0):
+def measure_single(pkg, n, D, J, steps, warmup, flags=0, inner_slabs=0):
     import torch
-    sim = pkg.FluidSim(n, diffusion_iters=D, pressure_iters=J, flags=flags)
+    sim = pkg.FluidSim(n, diffusion_iters=D, pressure_iters=J, flags=flags, inner_slabs=inner_slabs)
     seeded_warm_state(pkg, sim)
     sim.step(warmup)
     sim.prepare_steps(steps)   # builds the hipGraphs the timed call replays; runs nothing
@@ -310,6 +310,12 @@ def main():
                            "step_effective_GBps": round(b2 * n2 * n2 / t2 / 1e9, 1),
                            "step_frac_of_hbm_peak": round(b2 * n2 * n2 / t2 / 1e9 / HBM_PEAK_GBPS, 4)}
             s2.close()
+            if name == "4096_J40" and not flags:
+                # the same grid as two slabs side by side on the GPU (fluid_params.inner_slabs, opt-in:
+                # the slab contexts' advection reach applies); same bits, tests/test_inner_slabs.py
+                s3, w3 = measure_single(pkg, n2, D2, J2, k2, 16, flags, inner_slabs=2)
+                extra[name]["ms_per_step_inner_slabs_2"] = round(w3 / k2 * 1e3, 5)
+                s3.close()
         out["other_workloads"] = extra
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(pkg, D, J)

@@ -42,7 +42,7 @@ class FluidParams(C.Structure):
         ("n", C.c_int), ("diffusion_iters", C.c_int), ("pressure_iters", C.c_int),
         ("dt", C.c_float), ("viscosity", C.c_float), ("splat_radius", C.c_float),
         ("device", C.c_int), ("flags", C.c_uint), ("slab_rank", C.c_int), ("slab_count", C.c_int),
-        ("halo_rows", C.c_int), ("pressure_groups", C.c_int), ("ny", C.c_int), ("reserved", C.c_int * 3),
+        ("halo_rows", C.c_int), ("pressure_groups", C.c_int), ("ny", C.c_int), ("inner_slabs", C.c_int), ("reserved", C.c_int * 2),
     ]
 
 
@@ -248,7 +248,8 @@ class FluidSim:
                  pressure_iters: Optional[int] = None, dt: Optional[float] = None,
                  viscosity: Optional[float] = None, splat_radius: Optional[float] = None,
                  device: int = 0, flags: int = 0, slab_rank: int = 0, slab_count: int = 0,
-                 halo_rows: int = 0, pressure_groups: int = 0, ny: int = 0, lib: Optional[FluidLib] = None):
+                 halo_rows: int = 0, pressure_groups: int = 0, ny: int = 0, inner_slabs: int = 0,
+                 lib: Optional[FluidLib] = None):
         self.lib = lib or _get_default_lib()
         p = self.lib.default_params()
         if n is not None:
@@ -267,6 +268,7 @@ class FluidSim:
         p.slab_rank, p.slab_count, p.halo_rows = slab_rank, slab_count, halo_rows
         p.pressure_groups = pressure_groups
         p.ny = ny   # rows; 0 = n (square, the reference's case); n is then the number of columns
+        p.inner_slabs = inner_slabs   # >= 2: the domain as that many slabs side by side on this GPU (fluid.h)
         self.params = p
         self._h = C.c_void_p()
         rc = self.lib.dll.fluid_init(C.byref(self._h), C.byref(p))

@@ -116,6 +116,13 @@ struct fluid_ctx {
   long long comm_exchanges = 0, comm_bytes = 0;
   char comm_note[160] = {0};  // why graph capture was given up, if it was
   std::map<int, GraphEntry> comm_graphs;
+  // inner slabs (fluid_params.inner_slabs >= 2, "inner_*" below): this context owns no field; `subs`
+  // are the G slab contexts of the same GPU, stepped side by side on their own streams
+  std::vector<fluid_ctx *> subs;
+  hipEvent_t ev_fork = nullptr;     // this context's stream -> the slabs' streams
+  std::vector<hipEvent_t> ev_done;  // ... and back
+  bool inner_posted = false;        // the halo copies for the current state are enqueued
+  int inner_of = 0;                 // > 0: this context is one of that many inner slabs
   bool prof = false;
   int enq_rc = 0;          // first failure while enqueueing (a launch_* that refused, a failed memset); see check_launch
   std::vector<hipEvent_t> ev_pool;
@@ -683,6 +690,21 @@ void *field_ptr(fluid_ctx *c, int field, size_t *elem) {
 
 extern "C" {
 
+// inner slabs (fluid_params.inner_slabs >= 2): the whole-domain entry points of such a context
+static int inner_reset(fluid_ctx *P);
+static int inner_add_source(fluid_ctx *P, float sx, float sy, float fx, float fy, const float rgba[4]);
+static int inner_steps(fluid_ctx *P, int nsteps);
+static int inner_read(fluid_ctx *P, int field, void *dst, size_t dst_bytes);
+static int inner_write(fluid_ctx *P, int field, const void *src, size_t src_bytes);
+static int inner_sync(fluid_ctx *P);
+static int inner_diagnostics(fluid_ctx *P, fluid_diag *out);
+static int inner_time_steps(fluid_ctx *P, int nsteps, float *ms_out);
+static inline bool is_inner(const fluid_ctx *c) { return !c->subs.empty(); }
+#define NOT_ON_INNER(c, what)                                                                        \
+  do {                                                                                               \
+    if (is_inner(c)) return fail((c), FLUID_E_UNSUPPORTED, what " is not available with inner_slabs"); \
+  } while (0)
+
 int fluid_default_params(fluid_params *p) {
   if (!p) return FLUID_E_INVALID;
   memset(p, 0, sizeof *p);
@@ -731,13 +753,17 @@ int fluid_slab_plan(const fluid_params *p, fluid_slab_info *out) {
   return FLUID_OK;
 }
 
-int fluid_init(fluid_ctx **out, const fluid_params *p) {
+static int inner_init(fluid_ctx **out, const fluid_params &prm);
+
+// inner_of > 0: the context is one of that many inner slabs of a whole-domain context (inner_init)
+static int init_ctx(fluid_ctx **out, const fluid_params *p, int inner_of) {
   if (!out) return FLUID_E_INVALID;
   *out = nullptr;
   fluid_params prm;
   if (p) prm = *p; else fluid_default_params(&prm);
   if (prm.n < 4 || prm.diffusion_iters < 0 || prm.pressure_iters < 0) return FLUID_E_INVALID;
   if (prm.ny != 0 && prm.ny < 4) return FLUID_E_INVALID;
+  if (prm.inner_slabs < 0 || prm.reserved[0] || prm.reserved[1]) return FLUID_E_INVALID;
   fluid_slab_info si;
   int prc = fluid_slab_plan(&prm, &si);
   if (prc) return prc;
@@ -745,9 +771,11 @@ int fluid_init(fluid_ctx **out, const fluid_params *p) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return FLUID_E_DEVICE;  // no CPU fallback
   if (prm.device < 0 || prm.device >= ndev) return FLUID_E_INVALID;
+  if (prm.inner_slabs >= 2 && !inner_of) return inner_init(out, prm);
   fluid_ctx *c = new (std::nothrow) fluid_ctx();
   if (!c) return FLUID_E_NOMEM;
   c->prm = prm;
+  c->inner_of = inner_of;
   c->g = Geom{prm.n, si.store_row0, si.store_rows, prm.ny ? prm.ny : prm.n};
   c->row0 = si.row0;
   c->rows = si.rows;
@@ -782,6 +810,10 @@ int fluid_init(fluid_ctx **out, const fluid_params *p) {
   if (!tile_has_ty(c->tile_ty)) c->tile_ty = 32;
   c->tile_div = env_int("FLUID_TILE_DIV", 1) != 0;
   if (c->tile) { c->tb_kj = 10; c->tb_kd = 10; }
+  // Inner slabs share the GPU with their siblings: each launch is sized to its share of a resident
+  // round, and with the chunks that long the deep pipelines pay (tools/inner_slabs_probe.py).
+  else if (inner_of > 0 && owned < (1ll << 22)) { c->tb_kj = 10; c->tb_kd = 10; c->tb_waves = 2048 / inner_of; }
+  else if (inner_of > 0) { c->tb_kj = 14; c->tb_kd = 10; c->tb_waves = 4096 / inner_of; c->tb_waves_d = 3072 / inner_of; }
   else if (owned < (1ll << 23)) { c->tb_kj = 8; c->tb_kd = 10; c->tb_waves = 2048; }
   // From 2^24 to 2^26 owned cells (4096^2 ... 8192^2, slabs of 8 and 4 of 16384^2) a launch is sized to
   // exactly ONE resident round of workgroups at its own kernel's occupancy (tb_chunk: 4 waves per SIMD
@@ -796,7 +828,8 @@ int fluid_init(fluid_ctx **out, const fluid_params *p) {
   else { c->tb_kj = 14; c->tb_kd = 10; c->tb_waves = 16384; }
   // non-temporal stores in the two streaming kernels (fluid_kernels.hip): measured break-even at
   // about 3072^2 stored cells (2048^2: 0.204 -> 0.215 ms with them, 4096^2: 0.586 -> 0.570 ms)
-  c->nt_stores = env_int("FLUID_NT", (long long)prm.n * si.store_rows >= (1ll << 24) ? 1 : 0) != 0;
+  // (inner slabs: by the whole domain's size, what the GPU's caches see — 4096^2 as two slabs: 0.525 -> 0.515 ms)
+  c->nt_stores = env_int("FLUID_NT", (long long)prm.n * si.store_rows * (inner_of > 0 ? inner_of : 1) >= (1ll << 24) ? 1 : 0) != 0;
   c->graph_steps = env_int("FLUID_GRAPH_STEPS", 16);
   if (c->graph_steps < 1) c->graph_steps = 1;
   c->direct_parts = env_int("FLUID_DIRECT_PARTS", 1) != 0;
@@ -866,9 +899,14 @@ int fluid_init(fluid_ctx **out, const fluid_params *p) {
   return FLUID_OK;
 }
 
+int fluid_init(fluid_ctx **out, const fluid_params *p) { return init_ctx(out, p, 0); }
+
 void fluid_destroy(fluid_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->prm.device);
+  for (fluid_ctx *s : c->subs) fluid_destroy(s);
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  for (hipEvent_t e : c->ev_done) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
   drop_graphs(c);
@@ -888,6 +926,7 @@ void fluid_destroy(fluid_ctx *c) {
 
 int fluid_reset(fluid_ctx *c) {
   if (!c) return FLUID_E_INVALID;
+  if (is_inner(c)) return inner_reset(c);
   c->advect_early = false;  // rows advected ahead of the step are stale now (recomputed by the full launch)
   c->halo_state = 0;        // and so are halos already exchanged or on their way (fluid_comm_*)
   HIPCHK(c, hipSetDevice(c->prm.device));
@@ -900,6 +939,7 @@ int fluid_reset(fluid_ctx *c) {
 
 int fluid_add_source(fluid_ctx *c, float sx, float sy, float fx, float fy, const float rgba[4]) {
   if (!c || !rgba) return FLUID_E_INVALID;
+  if (is_inner(c)) return inner_add_source(c, sx, sy, fx, fy, rgba);
   c->advect_early = false;  // rows advected ahead of the step are stale now (recomputed by the full launch)
   c->halo_state = 0;
   HIPCHK(c, hipSetDevice(c->prm.device));
@@ -914,6 +954,7 @@ static int run_comm_steps(fluid_ctx *c, int nsteps);
 
 int fluid_step(fluid_ctx *c, int nsteps) {
   if (!c || nsteps < 0) return FLUID_E_INVALID;
+  if (is_inner(c)) return inner_steps(c, nsteps);
   if (c->slab && c->has_comm) {  // the library exchanges the halos itself (fluid_comm_attach*)
     HIPCHK(c, hipSetDevice(c->prm.device));
     return run_comm_steps(c, nsteps);
@@ -931,6 +972,7 @@ int fluid_step(fluid_ctx *c, int nsteps) {
 // (never read), so nothing has to be cleared between calls; it is shared by every call on the GPU.
 int fluid_step_noalloc(fluid_ctx *c, int nsteps) {
   if (!c || nsteps < 0) return FLUID_E_INVALID;
+  NOT_ON_INNER(c, "fluid_step_noalloc");
   if (c->slab) return FLUID_E_UNSUPPORTED;  // halos must be refreshed before every step (fluid_step_part)
   if (c->g.n > FLUID_NOALLOC_MAX_N)
     return fail(c, FLUID_E_SIZE, "fluid_step_noalloc: n = %d is beyond the static scratch (n <= %d, %zu bytes)",
@@ -955,7 +997,7 @@ int fluid_step_noalloc(fluid_ctx *c, int nsteps) {
 #define STAGE_FN(name, call, pre)                          \
   int name(fluid_ctx *c) {                                 \
     if (!c) return FLUID_E_INVALID;                        \
-    if (c->slab) return FLUID_E_UNSUPPORTED;               \
+    if (c->slab || is_inner(c)) return FLUID_E_UNSUPPORTED; \
     HIPCHK(c, hipSetDevice(c->prm.device));                \
     pre;                                                   \
     call;                                                  \
@@ -969,6 +1011,7 @@ STAGE_FN(fluid_advect_density, enq_advect_density(c), (void)0)
 
 int fluid_read(fluid_ctx *c, int field, void *dst, size_t dst_bytes) {
   if (!c || !dst) return FLUID_E_INVALID;
+  if (is_inner(c)) return inner_read(c, field, dst, dst_bytes);
   size_t elem = 0;
   char *src = (char *)field_ptr(c, field, &elem);
   if (!elem) return FLUID_E_INVALID;
@@ -988,6 +1031,7 @@ int fluid_read(fluid_ctx *c, int field, void *dst, size_t dst_bytes) {
 
 int fluid_write(fluid_ctx *c, int field, const void *srcv, size_t src_bytes) {
   if (!c || !srcv) return FLUID_E_INVALID;
+  if (is_inner(c)) return inner_write(c, field, srcv, src_bytes);
   c->advect_early = false;  // rows advected ahead of the step are stale now (recomputed by the full launch)
   c->halo_state = 0;
   if (field == FLUID_VORTICITY) {
@@ -1008,6 +1052,7 @@ int fluid_write(fluid_ctx *c, int field, const void *srcv, size_t src_bytes) {
 
 int fluid_sync(fluid_ctx *c) {
   if (!c) return FLUID_E_INVALID;
+  if (is_inner(c)) return inner_sync(c);
   HIPCHK(c, hipSetDevice(c->prm.device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (c->comm_stream) HIPCHK(c, hipStreamSynchronize(c->comm_stream));  // halos posted for the next step
@@ -1016,6 +1061,7 @@ int fluid_sync(fluid_ctx *c) {
 
 int fluid_diagnostics(fluid_ctx *c, fluid_diag *out) {
   if (!c || !out) return FLUID_E_INVALID;
+  if (is_inner(c)) return inner_diagnostics(c, out);
   HIPCHK(c, hipSetDevice(c->prm.device));
   if (!c->diag_partial) {
     const size_t rec_bytes = (size_t)DIAG_MAX_BLOCKS * DIAG_NREC * sizeof(float);
@@ -1065,6 +1111,7 @@ const char *fluid_last_error(const fluid_ctx *c) { return c ? c->err : ""; }
 
 int fluid_prepare_steps(fluid_ctx *c, int nsteps) {
   if (!c || nsteps < 0) return FLUID_E_INVALID;
+  if (is_inner(c)) return FLUID_OK;  // inner slabs enqueue their launches directly: nothing to build
   if (c->slab && nsteps > 1) return FLUID_E_UNSUPPORTED;
   if (c->groups > 1 && nsteps > 0) return FLUID_E_UNSUPPORTED;
   HIPCHK(c, hipSetDevice(c->prm.device));
@@ -1073,6 +1120,7 @@ int fluid_prepare_steps(fluid_ctx *c, int nsteps) {
 
 int fluid_time_steps(fluid_ctx *c, int nsteps, float *ms_out) {
   if (!c || nsteps < 0 || !ms_out) return FLUID_E_INVALID;
+  if (is_inner(c)) return inner_time_steps(c, nsteps, ms_out);
   if (c->slab && c->has_comm) return FLUID_E_UNSUPPORTED;  // time fluid_step from outside (two streams)
   if (c->slab && nsteps > 1) return FLUID_E_UNSUPPORTED;
   if (c->groups > 1 && nsteps > 0) return FLUID_E_UNSUPPORTED;  // as fluid_step: the exchanges between groups are the caller's
@@ -1101,6 +1149,7 @@ int fluid_time_steps(fluid_ctx *c, int nsteps, float *ms_out) {
 int fluid_profile_steps(fluid_ctx *c, int nsteps, fluid_kernel_stat *stats, int max_stats,
                         int *count) {
   if (!c || nsteps < 0 || !stats || !count || max_stats <= 0) return FLUID_E_INVALID;
+  NOT_ON_INNER(c, "fluid_profile_steps (per-launch events; the slabs' launches overlap)");
   if (c->slab && c->has_comm) return FLUID_E_UNSUPPORTED;  // per-launch events on one stream; the step runs on two
   if (c->slab && nsteps > 1) return FLUID_E_UNSUPPORTED;
   if (c->groups > 1 && nsteps > 0) return FLUID_E_UNSUPPORTED;
@@ -1139,6 +1188,7 @@ int fluid_profile_steps(fluid_ctx *c, int nsteps, fluid_kernel_stat *stats, int 
 
 int fluid_step_part(fluid_ctx *c, int part) {
   if (!c) return FLUID_E_INVALID;
+  NOT_ON_INNER(c, "fluid_step_part");
   switch (part) {
     case FLUID_PART_VELOCITY:
       if (c->groups > 1) return FLUID_E_UNSUPPORTED;
@@ -1541,10 +1591,281 @@ void *fluid_stream(fluid_ctx *c) { return c ? (void *)c->stream : nullptr; }
 int fluid_set_stream(fluid_ctx *c, void *hip_stream) {
   if (!c) return FLUID_E_INVALID;
   HIPCHK(c, hipSetDevice(c->prm.device));
+  if (is_inner(c)) {
+    const int rc = inner_sync(c);
+    if (rc) return rc;
+  }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   drop_graphs(c);
   c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
   return FLUID_OK;
+}
+
+// ---- inner slabs: one GPU's domain as G slabs side by side ---------------------------------------
+// No counterpart in the reference.  fluid_params.inner_slabs = G >= 2 makes fluid_init build G slab
+// contexts of the same GPU (the ordinary ones: own stream, own fields with halos, the step's
+// dependency cone recomputed in the halo) under a parent that owns no field.  The slabs of a step
+// are independent of each other, so their launches overlap on the GPU and fill each other's ramp-up
+// and drain (include/fluid.h).  Halo rows are PUSHED: each slab copies its own edge
+// rows into its neighbours' halo rows, on its own stream, so the source needs no cross-stream
+// ordering at all.  Per step and slab:
+//
+//   wait for my neighbours' pushes (ev_halo)   advection, diffusion -> ev_ready ("my halo rows of
+//   the buffers this step ends in are no longer read")   divergence + pressure sweeps   last kernel
+//   on the EDGE rows   wait for my neighbours' ev_ready, push my edge rows -> ev_halo   last kernel
+//   on the INTERIOR rows
+//
+// Why the destination is free after the diffusion: the last kernel writes the buffers the step ends
+// in; the velocity one of them was the input of the launch before it in the velocity chain (the last
+// diffusion launch, or the advection with D = 0), which read its halo rows — nothing later does; the
+// density one was last read a step ago.  Enqueue order on the host: every slab up to its edge rows,
+// then every slab's pushes and interior (all the events waited for are recorded by then).  A slab may
+// run ahead of its neighbour by the length of the interior launch and lag behind it by most of a step.
+static int inner_fail(fluid_ctx *P, const fluid_ctx *s, int rc) {
+  if (rc) snprintf(P->err, sizeof P->err, "inner slab %d: %.200s", s->prm.slab_rank, s->err);
+  return rc;
+}
+
+static int inner_init(fluid_ctx **out, const fluid_params &prm) {
+  const int G = prm.inner_slabs;
+  if (prm.slab_count > 1 || G > 16) return FLUID_E_UNSUPPORTED;  // no slabs of slabs
+  if (prm.flags & (FLUID_FLAG_VORTICITY | FLUID_FLAG_UNFUSED)) return FLUID_E_UNSUPPORTED;
+  fluid_ctx *P = new (std::nothrow) fluid_ctx();
+  if (!P) return FLUID_E_NOMEM;
+  P->prm = prm;
+  const int ny = prm.ny ? prm.ny : prm.n;
+  P->g = Geom{prm.n, 0, ny, ny};
+  P->rows = ny;
+  const int rc = [&]() -> int {
+    HIPCHK(P, hipSetDevice(prm.device));
+    HIPCHK(P, hipStreamCreateWithFlags(&P->own_stream, hipStreamNonBlocking));
+    P->stream = P->own_stream;
+    HIPCHK(P, hipEventCreateWithFlags(&P->ev_fork, hipEventDisableTiming));
+    for (int r = 0; r < G; ++r) {
+      fluid_params sp = prm;
+      sp.inner_slabs = 0;
+      sp.slab_rank = r;
+      sp.slab_count = G;
+      sp.pressure_groups = 0;
+      fluid_ctx *s = nullptr;
+      const int src = init_ctx(&s, &sp, G);
+      if (src) return src;  // e.g. FLUID_E_UNSUPPORTED: a slab too short for its halo
+      P->subs.push_back(s);
+      hipEvent_t e = nullptr;
+      HIPCHK(P, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      P->ev_done.push_back(e);
+      HIPCHK(P, hipEventCreateWithFlags(&s->ev_ready, hipEventDisableTiming));  // "my halo rows may be written"
+      HIPCHK(P, hipEventCreateWithFlags(&s->ev_halo, hipEventDisableTiming));   // "my pushes have landed"
+      s->interior_split = env_int("FLUID_INTERIOR_SPLIT", 1);  // nothing slow has to get in between: one launch
+      s->interior_split = s->interior_split < 1 ? 1 : s->interior_split > 8 ? 8 : s->interior_split;
+    }
+    return FLUID_OK;
+  }();
+  if (rc != FLUID_OK) {
+    fluid_destroy(P);
+    return rc;
+  }
+  *out = P;
+  return FLUID_OK;
+}
+
+// The slabs' streams pick up after this context's stream ...
+static int inner_fork(fluid_ctx *P) {
+  HIPCHK(P, hipSetDevice(P->prm.device));
+  HIPCHK(P, hipEventRecord(P->ev_fork, P->stream));
+  for (fluid_ctx *s : P->subs) HIPCHK(P, hipStreamWaitEvent(s->stream, P->ev_fork, 0));
+  return FLUID_OK;
+}
+// ... and it picks up after them (pushes included: they are on the slabs' streams).
+static int inner_join(fluid_ctx *P) {
+  for (size_t i = 0; i < P->subs.size(); ++i) {
+    HIPCHK(P, hipEventRecord(P->ev_done[i], P->subs[i]->stream));
+    HIPCHK(P, hipStreamWaitEvent(P->stream, P->ev_done[i], 0));
+  }
+  return FLUID_OK;
+}
+
+// Slab i's edge rows of the current velocity and density into its neighbours' halo rows, on its own
+// stream, once the neighbour no longer reads them (its ev_ready, recorded for the state in question).
+static int inner_push(fluid_ctx *P, size_t i) {
+  fluid_ctx *s = P->subs[i];
+  for (int dir = -1; dir <= 1; dir += 2) {
+    if (dir < 0 ? !s->has_lo : !s->has_hi) continue;
+    fluid_ctx *q = P->subs[i + dir];
+    HIPCHK(P, hipStreamWaitEvent(s->stream, q->ev_ready, 0));
+    for (int part : {FLUID_PART_VELOCITY, FLUID_PART_DENSITY}) {
+      HaloField fs, fq;
+      if (!halo_field(s, part, &fs) || !halo_field(q, part, &fq) || fq.rows <= 0) continue;
+      const size_t row = (size_t)s->g.n * fs.esize, bytes = fq.rows * row;
+      const size_t rs = dir < 0 ? s->own_r0 : s->own_r0 + s->rows - fq.rows;  // my owned rows next to that neighbour
+      const size_t rd = dir < 0 ? q->own_r0 + q->rows : q->own_r0 - fq.rows;  // its halo rows on my side
+      launch_copy_block(s->stream, fq.base + rd * row, fs.base + rs * row, bytes);
+    }
+  }
+  HIPCHK(P, hipEventRecord(s->ev_halo, s->stream));
+  return FLUID_OK;
+}
+
+// Halo rows for the current state, unless the pushes are already enqueued.
+static int inner_refresh(fluid_ctx *P) {
+  if (P->inner_posted) return FLUID_OK;
+  for (fluid_ctx *s : P->subs) HIPCHK(P, hipEventRecord(s->ev_ready, s->stream));
+  for (size_t i = 0; i < P->subs.size(); ++i) {
+    const int rc = inner_push(P, i);
+    if (rc) return rc;
+  }
+  P->inner_posted = true;
+  return FLUID_OK;
+}
+
+// A slab's stream waits for its neighbours' pushes into its halo rows.
+static int inner_wait_halos(fluid_ctx *P, size_t i) {
+  fluid_ctx *s = P->subs[i];
+  if (s->has_lo) HIPCHK(P, hipStreamWaitEvent(s->stream, P->subs[i - 1]->ev_halo, 0));
+  if (s->has_hi) HIPCHK(P, hipStreamWaitEvent(s->stream, P->subs[i + 1]->ev_halo, 0));
+  return FLUID_OK;
+}
+
+// nsteps steps of every slab, enqueue only (between inner_fork and inner_join)
+static int inner_enqueue(fluid_ctx *P, int nsteps) {
+  const size_t G = P->subs.size();
+  int rc;
+  for (int k = 0; k < nsteps; ++k) {
+    if ((rc = inner_refresh(P))) return rc;
+    for (size_t i = 0; i < G; ++i) {
+      fluid_ctx *s = P->subs[i];
+      if ((rc = inner_wait_halos(P, i))) return rc;
+      // enq_velocity_head in two pieces, with the event between them
+      const int m_diff = s->prm.pressure_iters + 1;
+      enq_advect_velocity(s, m_diff + s->prm.diffusion_iters);
+      enq_diffuse(s, m_diff);
+      HIPCHK(P, hipEventRecord(s->ev_ready, s->stream));
+      enq_pressure_group(s, 0);
+      enq_gradient_density_rows(s, true);  // the rows the neighbours wait for; flips to the new buffers
+    }
+    for (size_t i = 0; i < G; ++i) {
+      fluid_ctx *s = P->subs[i];
+      if ((rc = inner_push(P, i))) return rc;
+      enq_gradient_density_rows(s, false);
+      s->pgroup = 0;
+      s->tail_edges_done = false;
+      if ((rc = check_launch(s))) return inner_fail(P, s, rc);
+    }
+  }
+  return FLUID_OK;
+}
+
+// Direct launches: capturing the slabs' streams into one hipGraph (one branch per stream, events
+// waited for by several streams) crashed hipStreamEndCapture on ROCm 7.2 (host segfault, from either
+// origin stream) and was dropped; a step costs the host 50-90 us to enqueue for two slabs, which the
+// sizes this is for (>= 2048^2: >= 190 us per step) hide.
+static int inner_steps(fluid_ctx *P, int nsteps) {
+  int rc = inner_fork(P);
+  if (rc) return rc;
+  if ((rc = inner_enqueue(P, nsteps))) return rc;
+  return inner_join(P);
+}
+
+static int inner_reset(fluid_ctx *P) {
+  int rc = inner_fork(P);
+  for (size_t i = 0; i < P->subs.size() && !rc; ++i) rc = inner_fail(P, P->subs[i], fluid_reset(P->subs[i]));
+  P->inner_posted = false;
+  return rc ? rc : inner_join(P);
+}
+
+static int inner_add_source(fluid_ctx *P, float sx, float sy, float fx, float fy, const float rgba[4]) {
+  int rc = inner_fork(P);
+  for (size_t i = 0; i < P->subs.size() && !rc; ++i)
+    rc = inner_fail(P, P->subs[i], fluid_add_source(P->subs[i], sx, sy, fx, fy, rgba));
+  P->inner_posted = false;  // the halos hold the state before the splat
+  return rc ? rc : inner_join(P);
+}
+
+static size_t inner_elem(int field) {
+  switch (field) {
+    case FLUID_VELOCITY: return sizeof(float2);
+    case FLUID_DENSITY: return sizeof(float4);
+    case FLUID_PRESSURE: case FLUID_DIVERGENCE: case FLUID_VORTICITY: return sizeof(float);
+  }
+  return 0;
+}
+
+// The slabs' owned rows in y order: the whole grid, as a whole-domain context hands it out.
+static int inner_read(fluid_ctx *P, int field, void *dst, size_t dst_bytes) {
+  const size_t elem = inner_elem(field);
+  if (!elem) return FLUID_E_INVALID;
+  if (dst_bytes < (size_t)P->g.n * P->g.ny * elem) return FLUID_E_SIZE;
+  int rc = inner_fork(P);
+  for (size_t i = 0; i < P->subs.size() && !rc; ++i) {
+    fluid_ctx *s = P->subs[i];
+    rc = inner_fail(P, s, fluid_read(s, field, (char *)dst + (size_t)s->row0 * s->g.n * elem, cells_owned(s) * elem));
+  }
+  return rc;
+}
+
+static int inner_write(fluid_ctx *P, int field, const void *src, size_t src_bytes) {
+  const size_t elem = inner_elem(field);
+  if (!elem || field == FLUID_VORTICITY) return FLUID_E_INVALID;
+  if (src_bytes != (size_t)P->g.n * P->g.ny * elem) return FLUID_E_SIZE;
+  int rc = inner_fork(P);
+  for (size_t i = 0; i < P->subs.size() && !rc; ++i) {
+    fluid_ctx *s = P->subs[i];
+    rc = inner_fail(P, s, fluid_write(s, field, (const char *)src + (size_t)s->row0 * s->g.n * elem, cells_owned(s) * elem));
+  }
+  P->inner_posted = false;
+  return rc;
+}
+
+static int inner_sync(fluid_ctx *P) {
+  HIPCHK(P, hipSetDevice(P->prm.device));
+  HIPCHK(P, hipStreamSynchronize(P->stream));
+  for (fluid_ctx *s : P->subs) {
+    const int rc = fluid_sync(s);  // both of its streams, then its halo flag
+    if (rc) return inner_fail(P, s, rc);
+  }
+  return FLUID_OK;
+}
+
+// max over the slabs / sum over the slabs (the two stencil quantities read one halo row on each side)
+static int inner_diagnostics(fluid_ctx *P, fluid_diag *out) {
+  int rc = inner_fork(P);
+  if (!rc) rc = inner_refresh(P);
+  if (rc) return rc;
+  memset(out, 0, sizeof *out);
+  auto mx = [](float a, float b) { return a != a || b != b ? a + b : (a > b ? a : b); };  // NaN if either is
+  for (size_t i = 0; i < P->subs.size(); ++i) {
+    fluid_ctx *s = P->subs[i];
+    if ((rc = inner_wait_halos(P, i))) return rc;
+    fluid_diag d;
+    if ((rc = fluid_diagnostics(s, &d))) return inner_fail(P, s, rc);
+    out->max_abs_u = mx(out->max_abs_u, d.max_abs_u);
+    out->max_abs_v = mx(out->max_abs_v, d.max_abs_v);
+    out->max_abs_div = mx(out->max_abs_div, d.max_abs_div);
+    out->max_abs_p = mx(out->max_abs_p, d.max_abs_p);
+    out->max_jacobi_update = mx(out->max_jacobi_update, d.max_jacobi_update);
+    out->max_abs_div_velocity = mx(out->max_abs_div_velocity, d.max_abs_div_velocity);
+    for (int k = 0; k < 4; ++k) out->dye[k] += d.dye[k];
+  }
+  return inner_join(P);
+}
+
+static int inner_time_steps(fluid_ctx *P, int nsteps, float *ms_out) {
+  HIPCHK(P, hipSetDevice(P->prm.device));
+  hipEvent_t e0, e1;
+  HIPCHK(P, hipEventCreate(&e0));
+  HIPCHK(P, hipEventCreate(&e1));
+  const int rc = [&]() -> int {
+    HIPCHK(P, hipEventRecord(e0, P->stream));
+    const int r = inner_steps(P, nsteps);
+    if (r) return r;
+    HIPCHK(P, hipEventRecord(e1, P->stream));
+    HIPCHK(P, hipEventSynchronize(e1));
+    HIPCHK(P, hipEventElapsedTime(ms_out, e0, e1));
+    return FLUID_OK;
+  }();
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return rc;
 }
 
 }  // extern "C"

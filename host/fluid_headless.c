@@ -9,8 +9,9 @@
  *
  *   fluid_headless [--n N] [--ny ROWS] [--diffusion D] [--jacobi J] [--steps S] [--warmup W]
  *                  [--windows K] [--unfused] [--no-graph] [--vorticity] [--device I]
- *                  [--dump PREFIX] [--splats]
- *       timed run on the seeded splat script; prints one JSON line
+ *                  [--dump PREFIX] [--splats] [--inner-slabs G]
+ *       timed run on the seeded splat script; prints one JSON line (--inner-slabs: the domain as G
+ *       slabs side by side on the one GPU, fluid_params.inner_slabs)
  *
  *   ... --replay FILE [--frames F] [--window W H]
  *       replays a recorded session instead (kernel.cu:858-878, :813-856): events of frame f are
@@ -361,6 +362,7 @@ int main(int argc, char **argv) {
     else if (!strcmp(argv[i], "--halo-rows") && i + 1 < argc) prm.halo_rows = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--pressure-groups") && i + 1 < argc) prm.pressure_groups = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--comm-file") && i + 1 < argc) comm_file = argv[++i];
+    else if (!strcmp(argv[i], "--inner-slabs") && i + 1 < argc) prm.inner_slabs = atoi(argv[++i]); /* fluid.h: G slabs side by side on this GPU */
     else { fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
   }
   fluid_ctx *ctx = NULL;

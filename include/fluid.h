@@ -95,8 +95,27 @@ typedef struct fluid_params {
                           x < n, y < ny.  Every rule keeps its form with the extent taken per
                           axis (x tests and clamps against n, y tests and clamps against ny;
                           fluid_add_source normalises x by n and y by ny)                 */
-  int reserved[3];     /* must be zero                                        */
+  int inner_slabs;     /* whole-domain contexts: 0/1 = one context on one stream (default).  G >= 2
+                          = run the domain as G row slabs of THIS GPU side by side, one HIP
+                          stream each ("inner slabs", see below)                          */
+  int reserved[2];     /* must be zero                                        */
 } fluid_params;
+
+/*
+ * Inner slabs (fluid_params.inner_slabs = G >= 2; no counterpart in the reference).  The launches of a
+ * mid-size grid (2048^2 .. 8192^2) each fill the GPU for 30-100 us and lose a good part of that to
+ * their ramp-up and drain, and consecutive launches of one step depend on each other.  Two slabs of
+ * the same domain are independent for a whole step (the slab decomposition's one exchange per step,
+ * fluid_slab_plan), so their launches overlap on the GPU and fill each other's gaps: 4096^2, J = 40:
+ * 0.56 -> 0.50 ms per step with G = 2 on MI355X; nothing to gain at 16384^2.  The context behaves as a
+ * whole-domain context and gives the same bits (fluid_read / fluid_write / fluid_add_source /
+ * fluid_diagnostics / fluid_geometry see the whole grid; halo rows move between the slabs by
+ * device-side copies inside fluid_step), with these limits: the advection reach of slab contexts
+ * applies (halo_rows, FLUID_E_HALO if a backtrace is longer); FLUID_FLAG_VORTICITY and
+ * FLUID_FLAG_UNFUSED are refused (FLUID_E_UNSUPPORTED), and so are fluid_step_noalloc,
+ * fluid_profile_steps, the single-stage functions, fluid_step_part, fluid_halo_* and fluid_comm_*
+ * on such a context.  The shortest slab must hold a halo (fluid_slab_plan's rule).
+ */
 
 typedef struct fluid_ctx fluid_ctx;
 

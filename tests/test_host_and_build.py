@@ -111,6 +111,24 @@ def test_c_host_driver_matches_oracle(pkg, oracle, tmp_path):
         assert e <= 1e-5, (name, e)
 
 
+@pytest.mark.gpu
+def test_c_host_driver_with_inner_slabs_gives_the_same_bits(tmp_path):
+    """`fluid_headless --inner-slabs 2`: the same seeded run as two slabs side by side on the GPU
+    (fluid_params.inner_slabs) dumps the same bytes as the one-stream run."""
+    exe = os.path.join(ROOT, "host", "fluid_headless")
+    outs = []
+    for tag, extra in (("plain", []), ("inner", ["--inner-slabs", "2"])):
+        prefix = str(tmp_path / tag)
+        res = subprocess.run([exe, "--n", "1280", "--jacobi", "20", "--warmup", "12", "--steps", "3", "--windows", "2",
+                              "--dump", prefix] + extra, capture_output=True, text=True, timeout=300)
+        assert res.returncode == 0, res.stderr[-2000:]
+        json.loads(res.stdout.strip().splitlines()[-1])
+        outs.append({name: np.fromfile(f"{prefix}.{name}.f32", dtype=np.uint32)
+                     for name in ("velocity", "density", "pressure")})
+    for name in outs[0]:
+        assert outs[0][name].size > 0 and np.array_equal(outs[0][name], outs[1][name]), name
+
+
 EVENTS = [
     {"frame": 0, "type": "down", "x": 100, "y": 200},
     {"frame": 0, "type": "move", "x": 112, "y": 190},      # force (12, +10): y flipped, kernel.cu:872-873

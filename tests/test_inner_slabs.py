@@ -1,0 +1,163 @@
+"""Inner slabs (fluid_params.inner_slabs, include/fluid.h): one GPU's domain stepped as G row slabs
+side by side on G streams.  The context must behave as a whole-domain context and give the same
+bits: against the oracle from injected states, against the plain HIP context where add_source
+(expf) is involved, through every entry point a whole-domain context answers."""
+import numpy as np
+import pytest
+
+from util import FIELDS, assert_bit_equal, load_state, read_all, smooth_state
+
+pytestmark = pytest.mark.gpu
+
+E_INVALID, E_HALO, E_UNSUPPORTED = -1, -6, -7
+
+
+def test_error_codes_match_the_header(pkg):
+    import os
+    import re
+    text = open(os.path.join(os.path.dirname(__file__), "..", "include", "fluid.h")).read()
+    for name, val in (("FLUID_E_INVALID", E_INVALID), ("FLUID_E_HALO", E_HALO), ("FLUID_E_UNSUPPORTED", E_UNSUPPORTED)):
+        m = re.search(name + r"\s*=\s*(-?\d+)", text)
+        assert m and int(m.group(1)) == val, name
+
+
+@pytest.mark.parametrize("path", ["tiles", "pipeline"])
+@pytest.mark.parametrize("n,ny,D,J,G", [(192, 0, 10, 10, 2), (192, 0, 10, 10, 3), (256, 0, 10, 40, 2), (200, 0, 3, 7, 4),
+                                        (320, 200, 10, 10, 2), (128, 384, 5, 20, 3)])
+def test_inner_slabs_bit_exact_vs_oracle(pkg, hip, oracle, n, ny, D, J, G, path, monkeypatch):
+    """Whole steps from an injected state, several fluid_step calls of different lengths (the halo
+    copies between the slabs are posted inside a call and joined across calls): bit for bit."""
+    monkeypatch.setenv("FLUID_TILE", "1" if path == "tiles" else "0")
+    kw = dict(diffusion_iters=D, pressure_iters=J, ny=ny)
+    gpu = pkg.FluidSim(n, lib=hip, inner_slabs=G, **kw)
+    ref = pkg.FluidSim(n, lib=oracle, **kw)
+    rows = ny or n
+    assert (gpu.n, gpu.row0, gpu.rows) == (n, 0, rows)
+    big = smooth_state(max(n, rows), seed=11)
+    state = [np.ascontiguousarray(a[:rows, :n]) for a in big]
+    load_state(gpu, pkg, *state)
+    load_state(ref, pkg, *state)
+    for steps in (1, 2, 3):
+        gpu.step(steps)
+        ref.step(steps)
+        a, b = read_all(gpu, pkg), read_all(ref, pkg)
+        for f in FIELDS:
+            assert_bit_equal(a[f], b[f], f"{f} after {steps} more steps n={n} ny={ny} G={G} {path}")
+
+
+def drive(pkg, sim, script):
+    """The same calls on any context: splats, steps of several lengths, a field written half way, a
+    reset, more splats."""
+    ss = pkg.SplatStream()
+    out = []
+    for op in script:
+        if op == "splat":
+            sim.add_source(*ss.splat())
+        elif op == "reset":
+            sim.reset()
+        elif op == "write":
+            d = sim.read(pkg.FIELD_DENSITY)
+            sim.write(pkg.FIELD_DENSITY, d[::-1].copy())   # the picture upside down: every slab gets new rows
+        elif op == "diag":
+            out.append(sim.diagnostics())
+        elif op == "read":
+            out.append(read_all(sim, pkg))
+        else:
+            sim.step(int(op))
+    return out
+
+
+SCRIPT = ["splat", "splat", 2, "diag", "read", "splat", 1, "write", 3, "read", "diag", "reset", "read", "splat", 1, "splat", 2,
+          "read", "diag"]
+
+
+@pytest.mark.parametrize("n,J,G,env", [(512, 40, 2, {"FLUID_TILE": "0"}), (512, 10, 3, {}), (2048, 40, 2, {}),
+                                      (2048, 40, 4, {}), (1536, 25, 2, {}),
+                                      (768, 40, 2, {"FLUID_TILE": "0", "FLUID_TB_KJ": "5", "FLUID_TB_WAVES": "300"})])
+def test_inner_slabs_equal_the_plain_context(pkg, hip, n, J, G, env, monkeypatch):
+    """Splats between steps (they invalidate the halos), fluid_write, fluid_reset, diagnostics
+    across the seams: the same bits as the one-stream context, call for call."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    plain = pkg.FluidSim(n, lib=hip, pressure_iters=J)
+    inner = pkg.FluidSim(n, lib=hip, pressure_iters=J, inner_slabs=G)
+    a, b = drive(pkg, plain, SCRIPT), drive(pkg, inner, SCRIPT)
+    assert len(a) == len(b)
+    for i, (x, y) in enumerate(zip(a, b)):
+        if "velocity" in x:
+            for f in FIELDS:
+                assert_bit_equal(y[f], x[f], f"{f} at read {i} n={n} G={G}")
+        else:
+            for k in x:
+                if k == "dye":   # fp32 per block, double across blocks: the blocks differ
+                    np.testing.assert_allclose(y[k], x[k], rtol=1e-5, atol=1e-6)
+                else:
+                    assert np.float32(y[k]).view(np.uint32) == np.float32(x[k]).view(np.uint32), (k, x[k], y[k])
+    inner.sync()
+
+
+def test_inner_slabs_time_steps_and_streams(pkg, hip):
+    """fluid_time_steps brackets the slabs' work with events on the context's stream; work a caller
+    orders on that stream (fluid_set_stream) stays ordered around the steps."""
+    import torch
+    n = 1024
+    plain = pkg.FluidSim(n, lib=hip, pressure_iters=20)
+    inner = pkg.FluidSim(n, lib=hip, pressure_iters=20, inner_slabs=2)
+    ss_a, ss_b = pkg.SplatStream(), pkg.SplatStream()
+    plain.add_source(*ss_a.splat())
+    inner.add_source(*ss_b.splat())
+    plain.step(5)
+    ms = inner.time_steps(5)
+    assert 0.0 < ms < 1000.0
+    st = torch.cuda.Stream()
+    inner.set_stream(st.cuda_stream)
+    plain.step(4)
+    inner.step(4)
+    st.synchronize()   # the caller's stream alone: the slabs' streams were joined back into it
+    a, b = read_all(plain, pkg), read_all(inner, pkg)
+    for f in FIELDS:
+        assert_bit_equal(b[f], a[f], f)
+    inner.set_stream(0)
+    inner.step(1)
+    inner.sync()
+
+
+def test_inner_slabs_refusals(pkg, hip):
+    with pytest.raises(pkg.FluidError) as e:
+        pkg.FluidSim(256, lib=hip, inner_slabs=2, flags=pkg.FLAG_VORTICITY)
+    assert e.value.code == E_UNSUPPORTED
+    with pytest.raises(pkg.FluidError) as e:
+        pkg.FluidSim(256, lib=hip, inner_slabs=2, flags=pkg.FLAG_UNFUSED)
+    assert e.value.code == E_UNSUPPORTED
+    with pytest.raises(pkg.FluidError) as e:   # 16-row slabs cannot hold a 29-row halo
+        pkg.FluidSim(64, lib=hip, inner_slabs=4)
+    assert e.value.code == E_UNSUPPORTED
+    with pytest.raises(pkg.FluidError) as e:
+        pkg.FluidSim(256, lib=hip, inner_slabs=2, slab_rank=0, slab_count=2)
+    assert e.value.code == E_UNSUPPORTED
+    with pytest.raises(pkg.FluidError) as e:
+        pkg.FluidSim(256, lib=hip, inner_slabs=-1)
+    assert e.value.code == E_INVALID
+    sim = pkg.FluidSim(256, lib=hip, inner_slabs=2)
+    for call in (lambda: sim.step_noalloc(1), lambda: sim.profile_steps(1), lambda: sim.step_part(pkg.PART_VELOCITY),
+                 sim.advect_velocity, sim.project, sim.comm_refresh):
+        with pytest.raises(pkg.FluidError) as e:
+            call()
+        assert e.value.code == E_UNSUPPORTED
+    assert sim.halo_bytes(-1) == 0 and sim.halo_bytes(+1) == 0
+    sim.step(1)   # still usable
+    sim.sync()
+
+
+def test_inner_slabs_report_a_backtrace_beyond_the_halo(pkg, hip):
+    """The advection reach of slab contexts applies: a backtrace longer than halo_rows rows is
+    reported (FLUID_E_HALO), never a silently different result."""
+    n = 256
+    sim = pkg.FluidSim(n, lib=hip, inner_slabs=2, halo_rows=2)
+    vel = np.zeros((n, n, 2), np.float32)
+    vel[..., 1] = 100.0   # dt * v = 10 rows per step
+    sim.write(pkg.FIELD_VELOCITY, vel)
+    sim.step(1)
+    with pytest.raises(pkg.FluidError) as e:
+        sim.sync()
+    assert e.value.code == E_HALO
