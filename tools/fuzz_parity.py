@@ -4,7 +4,8 @@
   B. fused vs straight (FLUID_FLAG_UNFUSED) path, random grids up to 3000^2 incl. odd sizes
   C. slab groups (random count, split tail, pressure groups) vs the whole domain
   D. random launch plans (FLUID_TB_* / FLUID_TILE), whole domain and slabs, fused vs straight path
-Usage: python tools/fuzz_parity.py [seed] [cases_a cases_b cases_c cases_d]"""
+  E. inner slabs (fluid_params.inner_slabs) vs the one-stream context, random plans
+Usage: python tools/fuzz_parity.py [seed] [cases_a cases_b cases_c cases_d [cases_e]]"""
 import os
 import sys
 
@@ -187,4 +188,53 @@ for i in range(nd):
             break
     tst.close(); ref.close()
 print(f"D done ({nd} cases), mismatches {bad}", flush=True)
+
+# E: inner slabs (fluid_params.inner_slabs: G slab contexts side by side on the GPU, halo rows pushed
+# between their streams) against the one-stream context, random plans, several fluid_step calls of
+# random length with splats and a field write between them
+ne = int(sys.argv[6]) if len(sys.argv) > 6 else nd
+for i in range(ne):
+    for k in PLAN_ENV:
+        os.environ.pop(k, None)
+    G = int(rng.integers(2, 6))
+    D, J, A = int(rng.integers(0, 13)), int(rng.integers(0, 46)), int(rng.integers(1, 9))
+    need = J + 1 + D + A
+    n = int(rng.integers(max(G * (need + 4), 32), 1500 if rng.random() < 0.8 else 3000)) // 2 * 2
+    ny = int(rng.integers(max(G * (need + 4), 32), 1500)) if rng.random() < 0.3 else 0
+    env = {"FLUID_TB_KJ": int(rng.choice([2, 5, 8, 10, 14])), "FLUID_TB_KD": int(rng.choice([2, 5, 10])),
+           "FLUID_TB_WAVES": int(rng.choice([7, 64, 500, 2048])), "FLUID_TILE": int(rng.integers(0, 2))} if rng.random() < 0.6 else {}
+    ref = pkg.FluidSim(n, ny=ny, diffusion_iters=D, pressure_iters=J)
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        tst = pkg.FluidSim(n, ny=ny, diffusion_iters=D, pressure_iters=J, halo_rows=A, inner_slabs=G)
+    except pkg.FluidError as e:
+        print("skip", n, ny, G, D, J, A, env, e)
+        ref.close()
+        continue
+    finally:
+        for k in PLAN_ENV:
+            os.environ.pop(k, None)
+    ss_a, ss_b = pkg.SplatStream(), pkg.SplatStream()
+    ok = True
+    for s_ in range(3):
+        if rng.random() < 0.7:
+            ref.add_source(*ss_a.splat())
+            tst.add_source(*ss_b.splat())
+        if rng.random() < 0.2:
+            d = ref.read(pkg.FIELD_DENSITY)[:, ::-1].copy()
+            ref.write(pkg.FIELD_DENSITY, d)
+            tst.write(pkg.FIELD_DENSITY, d)
+        k = int(rng.integers(1, 4))
+        ref.step(k)
+        tst.step(k)
+        for name, fid in F:
+            if not same(tst.read(fid), ref.read(fid)):
+                bad += 1
+                ok = False
+                print("MISMATCH E", n, ny, G, D, J, A, env, name, "call", s_, flush=True)
+                break
+        if not ok:
+            break
+    tst.close(); ref.close()
+print(f"E done ({ne} cases), mismatches {bad}", flush=True)
 sys.exit(1 if bad else 0)
