@@ -821,7 +821,13 @@ static int init_ctx(fluid_ctx **out, const fluid_params *p, int inner_of) {
   // wave targets used before (tools/waves_sweep2.py): 6144^2 1.197 -> 1.085 ms, 8192^2 1.903 -> 1.826,
   // 8192^2 J=200 4.83 -> 4.43, 4096^2 and the slabs of 16384^2 within 1 %.  Smaller grids do better
   // under a round (2048 waves), larger ones with several (shorter chunks even out the end).
-  else if (owned < (1ll << 24)) { c->tb_kj = 8; c->tb_kd = 5; c->tb_waves = 2048; c->tb_waves_d = 2900; }  // (3900 before: 3072^2 0.353 -> 0.339 ms, slab of 8 of 8192^2 J=200 1.07 -> 1.01)
+  else if (owned < (1ll << 24)) {  // (waves_d 3900 before: 3072^2 0.353 -> 0.339 ms, slab of 8 of 8192^2 J=200 1.07 -> 1.01)
+    c->tb_kj = 8; c->tb_kd = 5; c->tb_waves = 2048; c->tb_waves_d = 2900;
+    // wide and short (a slab of 8 of 8192^2: 76 strips, few chunk rows): 10 sweeps per pressure launch,
+    // J = 200: 0.954 -> 0.886 ms per slab (J = 40: 0.344 -> 0.339); square grids of this size lose with
+    // it (3072^2 J = 200: 0.914 -> 1.060)
+    if (prm.n >= 4 * si.rows) c->tb_kj = 10;
+  }
   else if (owned < (1ll << 25)) { c->tb_kj = 10; c->tb_kd = 10; c->tb_waves = 3900; c->tb_waves_d = 2900; c->tb_rounds = 1.f; }
   else if (owned <= (1ll << 26)) { c->tb_kj = 14; c->tb_kd = 10; c->tb_waves = prm.n >= 12288 ? 3072 : 6100; c->tb_rounds = 1.f; }
   else if (owned <= (1ll << 27)) { c->tb_kj = 14; c->tb_kd = 10; c->tb_waves = 6100; }
