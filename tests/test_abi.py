@@ -22,6 +22,35 @@ def test_header_and_binding_agree(pkg):
     assert sorted(syms) == sorted(pkg.ABI_SYMBOLS)
 
 
+def test_ctypes_structures_have_the_layout_of_the_header(pkg, tmp_path):
+    """Every struct that crosses the C ABI: size and the offset of every field as gcc lays the
+    header's declaration out, against the ctypes mirror in capi.py (a field added on one side
+    only would shift everything behind it silently)."""
+    pairs = {"fluid_params": pkg.capi.FluidParams, "fluid_slab_info": pkg.capi.SlabInfo,
+             "fluid_kernel_stat": pkg.capi.KernelStat, "fluid_diag": pkg.capi.FluidDiag,
+             "fluid_transport": pkg.capi.FluidTransport, "fluid_comm_stats": pkg.capi.FluidCommStats}
+    lines = ['#include <stddef.h>', '#include <stdio.h>', f'#include "{os.path.join(ROOT, "include", "fluid.h")}"',
+             'int main(void) {']
+    for cname, cls in pairs.items():
+        lines.append(f'  printf("{cname} size %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{cname} {fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-o", str(exe), str(src)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    seen = 0
+    for line in out.splitlines():
+        cname, fname, val = line.split()
+        cls = pairs[cname]
+        want = C.sizeof(cls) if fname == "size" else getattr(cls, fname).offset
+        assert int(val) == want, f"{cname}.{fname}: header {val}, ctypes {want}"
+        seen += 1
+    assert seen == sum(len(c._fields_) + 1 for c in pairs.values())
+
+
 def test_hip_library_exports_every_declared_symbol(pkg):
     path = pkg.hip_lib_path()
     assert os.path.exists(path), "libfluid_hip.so must be built in-tree (see __graft_entry__.build)"
