@@ -46,6 +46,12 @@ constexpr int RING = TB_RING;
 #ifndef TB_STEADY
 #define TB_STEADY 1
 #endif
+#ifndef TB_RAMP
+#define TB_RAMP 1  // unrolled pipeline fill with only the levels each step needs (Pipe::ramp)
+#endif
+#ifndef TB_RAMP_MINK
+#define TB_RAMP_MINK 8
+#endif
 
 // value held by lane-1 / lane+1 (DPP wave shift; every lane must be active)
 __device__ __forceinline__ float from_left(float v) {
@@ -502,11 +508,12 @@ template <class Op, int K, bool XEDGE> struct Pipe {
     for (int j = K; j >= 1; --j) hh(j) = hh(j - 3);
   }
 
-  template <int J, bool YCHK>
+  // LV: levels evaluated (K in the general step; fewer while the pipeline fills, see ramp())
+  template <int J, bool YCHK, int LV = K>
   __device__ __forceinline__ R levels(const P &p, int t, const A &cur) {
     R fin = Op::zero();
 #pragma unroll
-    for (int l = 0; l < K; ++l) {
+    for (int l = 0; l < LV; ++l) {
       A d = cur;  // a copy of the value (never a select between two rows' addresses)
       if (l > 0) d = hh(l + 1 - J % 3);
       R o = Op::template apply<XEDGE, YCHK>(s[l][J % 3], s[l][(J + 1) % 3], s[l][(J + 2) % 3], d,
@@ -536,6 +543,46 @@ template <class Op, int K, bool XEDGE> struct Pipe {
     else fin = levels<J, true>(p, t, cur);
     const int ro = t - K;  // level K row just produced
     Op::store_at(Op::out_ptr(p, st_ok && ro >= ya && ro < yb, off(ro), (size_t)xc), fin);
+  }
+
+  // The first 2K steps of a chunk fill the pipeline: level L is first needed for row ya - (K - L),
+  // which is produced in step t0 + 2L, so step t0 + j needs only the levels up to j / 2 (everything
+  // deeper would be computed from rows outside the dependency cone of the rows this chunk stores,
+  // and nothing that is stored ever reads it).  The general step evaluates all K levels every time:
+  // K^2 of a chunk's (chunk + 2K) * K level evaluations, 16 % at 4096^2 (41-row chunks, K = 10).
+  // These steps are therefore unrolled with a compile-time level count — straight-line code, same
+  // register slots, no conditional slot writes (a run-time bound inside the general step cost
+  // 25-60 VGPRs).  Nothing is stored before step t0 + 2K (row t0 + 2K - K = ya).
+  static constexpr int RAMP = TB_RAMP && K >= TB_RAMP_MINK ? (2 * K + RING - 1) / RING * RING : 0;
+  template <int JJ, bool YCHK>
+  __device__ __forceinline__ void ramp_step(const P &p, int t) {
+    constexpr int J = JJ % RING;
+    constexpr int LV = JJ / 2 < K ? JJ / 2 : K;
+    if (J % 3 == 0) shift_aux();
+    const A cur = feed.template cur<J>(*this, p, off(t - 1 + RING));
+    if constexpr (Op::kLoadsField) {
+      s[0][(J + 2) % 3] = pf[J % RING];
+      pf[J % RING] = Op::load(p, off(t + RING));
+    }
+    if constexpr (Op::kStoresAux) {
+      const bool areal = st_ok && t >= ya && t < yb;
+      feed.template produce<J, true>(*this, p, t, off(t + 1 + RING),
+                                     areal ? p.div_out + off(t) : p.dump + (size_t)g.n + xc);
+    }
+    if constexpr (LV > 0) {
+      const R fin = levels<J, YCHK, LV>(p, t, cur);
+      if constexpr (LV == K) {
+        const int ro = t - K;
+        Op::store_at(Op::out_ptr(p, st_ok && ro >= ya && ro < yb, off(ro), (size_t)xc), fin);
+      }
+    }
+  }
+  template <int JJ, bool YCHK>
+  __device__ __forceinline__ void ramp(const P &p, int t0) {
+    if constexpr (JJ < RAMP) {
+      ramp_step<JJ, YCHK>(p, t0 + JJ);
+      ramp<JJ + 1, YCHK>(p, t0);
+    }
   }
 
   // Steady state: every level's row is y-interior, the produced row (and divergence row) is one
@@ -587,7 +634,11 @@ template <class Op, int K, bool XEDGE> struct Pipe {
     // general steps up to the steady window, the window, general steps to the end: one copy of
     // the general loop's code, run twice (up to RING-1 surplus steps at the end: loads are
     // clamped, stores dumped)
-    int t = t0;
+    // (one instantiation, with the y-border tests: a second one without them for the chunks that
+    // touch no border was measured — nothing at 4096^2 and up, 178 -> 190 us per step at 2048^2,
+    // where the extra code costs more than the tests)
+    ramp<0, true>(p, t0);
+    int t = t0 + RAMP;  // a multiple of RING: the phase of the general loop is unchanged
     int gend = TB_STEADY && Op::kSteady && tea >= tsa ? min(tsa, t1) : t1;
 #pragma nounroll
     for (int pass = 0; pass < 2; ++pass) {
