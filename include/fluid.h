@@ -107,7 +107,7 @@ typedef struct fluid_params {
  * their ramp-up and drain, and consecutive launches of one step depend on each other.  Two slabs of
  * the same domain are independent for a whole step (the slab decomposition's one exchange per step,
  * fluid_slab_plan), so their launches overlap on the GPU and fill each other's gaps: 4096^2, J = 40:
- * 0.56 -> 0.50 ms per step with G = 2 on MI355X; nothing to gain at 16384^2.  The context behaves as a
+ * 0.53 -> 0.50 ms per step with G = 2 on MI355X (0.48 with 3); nothing to gain at 16384^2.  The context behaves as a
  * whole-domain context and gives the same bits (fluid_read / fluid_write / fluid_add_source /
  * fluid_diagnostics / fluid_geometry see the whole grid; halo rows move between the slabs by
  * device-side copies inside fluid_step), with these limits: the advection reach of slab contexts
