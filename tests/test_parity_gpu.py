@@ -411,6 +411,31 @@ def test_temporal_blocking_every_phase_at_the_borders(pkg, hip, oracle, k, cols,
                 assert_bit_equal(a[f], b[f], f"{stage}/{f} n={n} k={k} cols={cols}")
 
 
+@pytest.mark.parametrize("chunk_rows", [1, 3, 7, 20, 33])
+@pytest.mark.parametrize("k", [8, 10, 13, 14])
+def test_pipeline_fill_with_chunks_shorter_and_longer_than_the_fill(pkg, hip, oracle, k, chunk_rows, monkeypatch):
+    """The first 2k steps of a chunk are unrolled with only the levels each step needs
+    (Pipe::ramp).  Chunks of every length against that fill — shorter than it (the whole chunk is
+    fill and flush), equal, longer — and every alignment of chunk boundaries with the y borders:
+    bit for bit against the sweep-by-sweep oracle, whole steps, two in a row."""
+    n = 150
+    monkeypatch.setenv("FLUID_TILE", "0")
+    monkeypatch.setenv("FLUID_TB_KJ", str(k))
+    monkeypatch.setenv("FLUID_TB_KD", str(min(k, 10)))
+    monkeypatch.setenv("FLUID_TB_MINCHUNK", "0")
+    monkeypatch.setenv("FLUID_TB_WAVES", str(2 * ((n + chunk_rows - 1) // chunk_rows)))   # two strips: chunks of chunk_rows rows
+    gpu, ref = pair(pkg, hip, oracle, n, diffusion_iters=min(k, 10) + 3, pressure_iters=2 * k + 1)
+    state = smooth_state(n, seed=k + chunk_rows)
+    load_state(gpu, pkg, *state)
+    load_state(ref, pkg, *state)
+    for _ in range(2):
+        gpu.step(1)
+        ref.step(1)
+        a, b = read_all(gpu, pkg), read_all(ref, pkg)
+        for f in FIELDS:
+            assert_bit_equal(a[f], b[f], f"{f} k={k} chunk={chunk_rows}")
+
+
 @pytest.mark.parametrize("ty", [32, 16])
 @pytest.mark.parametrize("k", [1, 2, 4, 5, 8, 10])
 def test_lds_tiles_bit_exact(pkg, hip, oracle, k, ty, monkeypatch):
