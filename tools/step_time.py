@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """ms per step (HIP events, min of 3 windows) and per-kernel times for a few whole-domain sizes.
-Usage: tools/step_time.py [n:J ...]   (environment knobs such as FLUID_TAIL_ADVECT apply)"""
+Usage: tools/step_time.py [n:J ...]   (FLUID_TB_* / FLUID_TILE / FLUID_NT apply; FLUID_HIP_LIB=path times an experimental build)"""
 import os
 import sys
 
