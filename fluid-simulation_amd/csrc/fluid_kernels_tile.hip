@@ -90,6 +90,7 @@ template <int K, int TY> struct Run {
   int c0;      // LDS index of the run's first segment
   int cm, cp;  // LDS index of the segment above the run / below it (clamped into the tile)
   int x, y;    // global coordinates of the run's first cell
+  int ly;      // tile row of the run's first row
   bool active;
   // TILE_BORDER: the run's segment holds column 0 / column n-1 (its first / last cell: n % 4 == 0);
   // row j of the run is row 0 / row n-1; the segment lies inside the domain in x
@@ -106,6 +107,7 @@ template <int K, int TY> struct Run {
     cp = ly0 + R < G::H ? c0 + R * G::W : c0 + (R - 1) * G::W;
     x = x_org + 4 * sx;
     y = y_org + ly0;
+    ly = ly0;
     bx0 = x == 0;
     bx1 = x + 3 == n - 1;
     in_x = x >= 0 && x < n;
@@ -116,6 +118,17 @@ template <int K, int TY> struct Run {
       by1[j] = y + j == ny - 1;
       yb = yb || by0[j] || by1[j];
     }
+  }
+  // Does anything that is stored depend on what sweep s (0-based) makes of this run?  The cells a
+  // sweep must get right shrink by one ring per sweep towards the stored centre: sweep s produces
+  // iterate s + 1, which is needed on the tile rows [s + 1, H - 2 - s] only (the centre plus the
+  // K - 1 - s rings the remaining sweeps still reach across).  Runs wholly above or below that are
+  // skipped: their cells go stale, and only cells that are skipped themselves ever read them.
+  // Runs are numbered row by row, so whole waves fall outside — the first and the last wave of a
+  // 64 x 32 tile in half of its ten sweeps.  (The same holds for columns, but a wave spans every
+  // column: nothing to skip there.)
+  __device__ __forceinline__ bool need(int s) const {
+    return ly + R - 1 >= s + 1 && ly <= TileGeom<K, TY>::H - 2 - s;
   }
 };
 
@@ -298,7 +311,7 @@ __global__ __launch_bounds__((TileGeom<K, TY>::THREADS)) void k_jacobi_tile(Geom
   __syncthreads();
 #pragma unroll 1
   for (int s = 0; s < K; ++s) {
-    if (rn.active) run_sweep<K, TY, JacobiRule>(a, b, rn, ce, dv, mode, n, g.ny, 0.0f, 0.0f);
+    if (rn.active && rn.need(s)) run_sweep<K, TY, JacobiRule>(a, b, rn, ce, dv, mode, n, g.ny, 0.0f, 0.0f);
     __syncthreads();
     float *t = a; a = b; b = t;
   }
@@ -369,7 +382,7 @@ __global__ __launch_bounds__((TileGeom<K + (DIV ? 1 : 0), TY>::THREADS)) void k_
   __syncthreads();
 #pragma unroll 1
   for (int s = 0; s < K; ++s) {
-    if (rn.active) {
+    if (rn.active && rn.need(s)) {
       run_sweep<HALO, TY, DiffuseRule>(au, bu, rn, cu, none, mode, n, g.ny, alpha, beta);
       run_sweep<HALO, TY, DiffuseRule>(aw, bw, rn, cw, none, mode, n, g.ny, alpha, beta);
     }
