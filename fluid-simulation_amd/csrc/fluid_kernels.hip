@@ -147,7 +147,7 @@ constexpr int ADV_ROWS_DENS = ADV_RD;  // float4 texels: more rows cost occupanc
 
 // kernel.cu:114-140
 // ADV_ROWS: rows per thread.  Four on the grids that matter for bandwidth; one on the smallest
-// (up to ~600^2), where a launch is a single wave of workgroups and what counts is how many
+// (up to ~1100^2: 768^2 8.9 -> 7.1 us, 1024^2 10.2 -> 9.6), where a launch is a wave or two of workgroups and what counts is how many
 // lanes share the two dependent round trips (512^2, J = 10: 26.4 -> 25.0 us per step).
 template <bool NT, int ADV_ROWS>
 __global__ __launch_bounds__(BX *BY) void k_advect_vel(Geom g, int r0, int r1, Rows second, Valid valid, float dt,
@@ -450,7 +450,7 @@ void launch_advect_vel(hipStream_t s, Geom g, int r0, int r1, int vlo, int vhi, 
   if (r1 <= r0) { r0 = r0b; r1 = r1b; r0b = r1b = 0; }
   if (r1 <= r0) return;
   const bool two = r1b > r0b;
-  const bool small = (long long)g.n * g.L <= 3 * (1ll << 17);  // see k_advect_vel
+  const bool small = (long long)g.n * g.L <= 5 * (1ll << 18);  // see k_advect_vel
   const int rows_per_thread = small ? 1 : ADV_ROWS_VEL;
   dim3 grid = grid_adv(g, r0, r1, rows_per_thread);
   if (two) {
