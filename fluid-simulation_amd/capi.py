@@ -21,7 +21,7 @@ _FIELD_COMPONENTS = {FIELD_VELOCITY: 2, FIELD_DENSITY: 4, FIELD_PRESSURE: 1, FIE
 # Every symbol include/fluid.h declares (checked against the header text in tests).
 ABI_SYMBOLS = [
     "fluid_default_params", "fluid_init", "fluid_destroy", "fluid_reset", "fluid_add_source",
-    "fluid_step", "fluid_prepare_steps", "fluid_step_noalloc", "fluid_advect_velocity", "fluid_diffuse", "fluid_vorticity", "fluid_project",
+    "fluid_step", "fluid_prepare_steps", "fluid_step_noalloc", "fluid_debug_sink", "fluid_advect_velocity", "fluid_diffuse", "fluid_vorticity", "fluid_project",
     "fluid_advect_density", "fluid_read", "fluid_write", "fluid_sync", "fluid_diagnostics", "fluid_geometry",
     "fluid_strerror", "fluid_last_error", "fluid_time_steps", "fluid_profile_steps",
     "fluid_stream", "fluid_set_stream",
@@ -146,6 +146,7 @@ class FluidLib:
         sig("fluid_step", C.c_int, P, C.c_int)
         sig("fluid_prepare_steps", C.c_int, P, C.c_int, required=False)
         sig("fluid_step_noalloc", C.c_int, P, C.c_int, required=False)
+        sig("fluid_debug_sink", C.c_int, P, C.c_int, C.c_int, C.c_uint, C.POINTER(C.c_longlong), required=False)
         for s in ("fluid_advect_velocity", "fluid_diffuse", "fluid_vorticity", "fluid_project",
                   "fluid_advect_density", "fluid_sync"):
             sig(s, C.c_int, P)
@@ -325,6 +326,14 @@ class FluidSim:
     def step_noalloc(self, nsteps: int = 1):
         """fluid_step_noalloc: the same steps by direct launches out of static scratch; allocates nothing."""
         self._chk(self.lib.dll.fluid_step_noalloc(self._h, nsteps), "fluid_step_noalloc")
+
+    def debug_sink(self, which: int, fill: bool, pattern: int = 0x5A5A5A5A) -> int:
+        """fluid_debug_sink: fill the context's own sink row (which=0) or the GPU's static scratch
+        (which=1) with `pattern`, or (fill=False) count the words that no longer hold it."""
+        d = C.c_longlong(-1)
+        self._chk(self.lib.dll.fluid_debug_sink(self._h, which, int(fill), pattern, None if fill else C.byref(d)),
+                  "fluid_debug_sink")
+        return d.value
 
     def prepare_steps(self, nsteps: int):
         """fluid_prepare_steps: build the graphs step(nsteps) replays, without running anything."""

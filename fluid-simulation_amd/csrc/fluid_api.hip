@@ -852,12 +852,15 @@ static int init_ctx(fluid_ctx **out, const fluid_params *p, int inner_of) {
   if (env_int("FLUID_TB_WAVES", 0) > 0) c->tb_rounds = 0.f;  // an explicit wave target wins over the table's rounds
   c->tb_rounds = env_int("FLUID_TB_ROUNDS_PCT", (int)(c->tb_rounds * 100.f + 0.5f)) / 100.f;
   c->tb_minchunk = env_int("FLUID_TB_MINCHUNK", c->tb_minchunk);
-  fill_pass_tables(c);
   c->alpha = 1.0f / (prm.viscosity * prm.dt);  // kernel.cu:182, fp32 at run time
   c->beta = 1.0f / (4.0f + c->alpha);          // kernel.cu:183
   int rc = [&]() -> int {
     HIPCHK(c, hipSetDevice(prm.device));
-    HIPCHK(c, scratch_setup(prm.device));  // this device's copy of the static scratch (fluid_step_noalloc)
+    fill_pass_tables(c);  // asks the runtime for occupancies: on this context's device, hence after hipSetDevice
+    // this device's copy of the static scratch (fluid_step_noalloc).  A failed lookup (or a device
+    // ordinal beyond the table) only disables that one entry point: it reports the missing address itself.
+    (void)scratch_setup(prm.device);
+    (void)hipGetLastError();
     HIPCHK(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     const size_t nc = cells_local(c);
@@ -984,7 +987,11 @@ int fluid_step_noalloc(fluid_ctx *c, int nsteps) {
     return fail(c, FLUID_E_SIZE, "fluid_step_noalloc: n = %d is beyond the static scratch (n <= %d, %zu bytes)",
                 c->g.n, FLUID_NOALLOC_MAX_N, FLUID_NOALLOC_SCRATCH_BYTES);
   if ((size_t)c->g.n * 16 + 256 > FLUID_NOALLOC_SCRATCH_BYTES) return FLUID_E_SIZE;
-  void *const ptr = g_scratch_ptr[c->prm.device];  // set by fluid_init on this device
+  void *ptr = nullptr;  // set by fluid_init on this device
+  if (c->prm.device >= 0 && c->prm.device < kMaxDevices) {
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    ptr = g_scratch_ptr[c->prm.device];
+  }
   if (!ptr) return fail(c, FLUID_E_DEVICE, "fluid_step_noalloc: no scratch address for device %d", c->prm.device);
   HIPCHK(c, hipSetDevice(c->prm.device));
   void *const own_dump = c->dump;
@@ -996,6 +1003,37 @@ int fluid_step_noalloc(fluid_ctx *c, int nsteps) {
   }
   c->dump = own_dump;
   return rc;
+}
+
+// Test hook (include/fluid.h): lets a test see WHICH sink row the temporally blocked kernels were
+// handed — the context's own hipMalloc'ed dump row (which = 0) or this GPU's static scratch
+// (which = 1, its first n * 16 + 256 bytes).  fill: every 32-bit word := pattern, on the context's
+// stream.  differing: after a synchronise, the number of words that are not `pattern`.
+int fluid_debug_sink(fluid_ctx *c, int which, int fill, unsigned pattern, long long *differing) {
+  if (!c || which < 0 || which > 1) return FLUID_E_INVALID;
+  NOT_ON_INNER(c, "fluid_debug_sink");
+  void *ptr = c->dump;
+  if (which == 1) {
+    ptr = nullptr;
+    if (c->prm.device >= 0 && c->prm.device < kMaxDevices) {
+      std::lock_guard<std::mutex> lock(g_scratch_mutex);
+      ptr = g_scratch_ptr[c->prm.device];
+    }
+    if ((size_t)c->g.n * 16 + 256 > FLUID_NOALLOC_SCRATCH_BYTES) return FLUID_E_SIZE;
+  }
+  if (!ptr) return fail(c, FLUID_E_DEVICE, "fluid_debug_sink: no such row on device %d", c->prm.device);
+  const size_t words = ((size_t)c->g.n * 16 + 256) / 4;
+  HIPCHK(c, hipSetDevice(c->prm.device));
+  if (fill) HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)ptr, (int)pattern, words, c->stream));
+  if (differing) {
+    std::vector<unsigned> host(words);
+    HIPCHK(c, hipMemcpyAsync(host.data(), ptr, words * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    long long d = 0;
+    for (unsigned w : host) d += w != pattern;
+    *differing = d;
+  }
+  return FLUID_OK;
 }
 
 // Single stages are whole-domain only: in a slab the row range a stage must cover depends on
@@ -1766,6 +1804,14 @@ static int inner_enqueue(fluid_ctx *P, int nsteps) {
 // origin stream) and was dropped; a step costs the host 50-90 us to enqueue for two slabs, which the
 // sizes this is for (>= 2048^2: >= 190 us per step) hide.
 static int inner_steps(fluid_ctx *P, int nsteps) {
+  // Under the caller's stream capture (fluid_set_stream + hipStreamBeginCapture) the fork below would
+  // pull the G sibling streams, with their waits on each other's events, into that capture: the shape
+  // that crashed the runtime (above).  Refused, not attempted.
+  HIPCHK(P, hipSetDevice(P->prm.device));
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(P->stream, &cap) != hipSuccess) (void)hipGetLastError();
+  if (cap != hipStreamCaptureStatusNone)
+    return fail(P, FLUID_E_UNSUPPORTED, "fluid_step on an inner_slabs context cannot run under stream capture");
   int rc = inner_fork(P);
   if (rc) return rc;
   if ((rc = inner_enqueue(P, nsteps))) return rc;

@@ -20,6 +20,8 @@
 // K fused sweeps are bit-identical to K launches of the straight kernels.
 #include "fluid_internal.h"
 
+#include <mutex>
+
 #pragma clang fp contract(off)
 
 namespace {
@@ -873,9 +875,15 @@ bool occ_dispatch(int kind, int k, int cols, int *out) {
 }
 }  // namespace
 int tb_resident_blocks(int kind, int k, int cols) {
-  static int cache[3][16][5];  // 0 = not asked yet, -1 = unknown
+  // per device (the answer is the current device's: callers have set the context's), one lock for all
+  constexpr int kDevs = 64;
+  static int cache[kDevs][3][16][5];  // 0 = not asked yet, -1 = unknown
+  static std::mutex mu;
+  int dev = 0;
   if (kind < 0 || kind > 2 || k < 1 || k > 15 || cols < 1 || cols > 4) return 0;
-  int &slot = cache[kind][k][cols];
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kDevs) return 0;
+  std::lock_guard<std::mutex> lock(mu);
+  int &slot = cache[dev][kind][k][cols];
   if (slot == 0) {
     int v = 0;
     slot = occ_dispatch(kind, k, cols, &v) && v > 0 ? v : -1;

@@ -256,7 +256,15 @@ static int write_view(fluid_ctx *ctx, int n, int rows, int view, int width, int 
   float *fld = (float *)malloc(sizeof(float) * comps * (size_t)n * rows);
   float *img = (float *)calloc(4 * (size_t)width * height, sizeof(float));
   if (!fld || !img) { free(fld); free(img); return 1; }
-  CHECK(fluid_read(ctx, field_of[view], fld, sizeof(float) * comps * (size_t)n * rows));
+  {
+    const int rrc = fluid_read(ctx, field_of[view], fld, sizeof(float) * comps * (size_t)n * rows);
+    if (rrc) {
+      fprintf(stderr, "fluid_read failed: %s (%s)\n", fluid_strerror(rrc), fluid_last_error(ctx));
+      free(fld);
+      free(img);
+      return 1;
+    }
+  }
   for (int y = 0; y < height && y < rows; ++y)    /* threads exist for id < n only, kernel.cu:439-440 */
     for (int x = 0; x < width && x < n; ++x) {
       const size_t t = (size_t)y * n + x;         /* tex2D(tex, id.x, id.y), point filter: texel (x, y) */

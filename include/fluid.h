@@ -167,6 +167,14 @@ FLUID_API int fluid_prepare_steps(fluid_ctx *ctx, int nsteps);
 #define FLUID_NOALLOC_MAX_N 16384
 FLUID_API int fluid_step_noalloc(fluid_ctx *ctx, int nsteps);
 
+/* Test hook for the above; no counterpart in the reference and not part of the solver.  The sink
+ * row is write-only, so results cannot show which one the kernels were handed: the context's own
+ * (which = 0) or this GPU's static scratch (which = 1; its first n * 16 + 256 bytes, the part a
+ * grid of width n uses).  fill != 0: every 32-bit word of that row := pattern, on the context's
+ * stream.  differing != NULL: synchronise and store the number of words that are not `pattern`.
+ * (Allocates host memory: it is a checker, not a no-allocation entry point.) */
+FLUID_API int fluid_debug_sink(fluid_ctx *ctx, int which, int fill, unsigned pattern, long long *differing);
+
 /* The four stage functions simulationStep() is made of, individually
  * (kernel.cu:542-555, :582-602, :604-662, :664-685) and the optional
  * simulateVorticity() (:557-580).  fluid_step == advect_velocity, diffuse,

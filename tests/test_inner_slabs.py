@@ -161,3 +161,31 @@ def test_inner_slabs_report_a_backtrace_beyond_the_halo(pkg, hip):
     with pytest.raises(pkg.FluidError) as e:
         sim.sync()
     assert e.value.code == E_HALO
+
+
+def test_inner_slabs_refuse_the_callers_stream_capture(pkg, hip):
+    """fluid_set_stream accepts an inner_slabs context, and a step under the caller's
+    capture would pull the G sibling streams (cross-stream event waits) into that capture — the
+    shape that crashed hipStreamEndCapture.  The library refuses it (FLUID_E_UNSUPPORTED) and
+    the capture, in which nothing was enqueued, still ends cleanly; afterwards the context works."""
+    import torch
+    n = 512
+    plain = pkg.FluidSim(n, lib=hip)
+    inner = pkg.FluidSim(n, lib=hip, inner_slabs=2)
+    for s in (plain, inner):
+        s.add_source(0.5, 0.5, 10.0, -5.0)
+    st = torch.cuda.Stream()
+    inner.set_stream(st.cuda_stream)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(st):
+        graph.capture_begin(capture_error_mode="relaxed")
+        with pytest.raises(pkg.FluidError) as e:
+            inner.step(1)
+        graph.capture_end()
+    assert e.value.code == E_UNSUPPORTED and "capture" in str(e.value)
+    inner.set_stream(0)
+    plain.step(2)
+    inner.step(2)
+    a, b = read_all(plain, pkg), read_all(inner, pkg)
+    for f in FIELDS:
+        assert_bit_equal(b[f], a[f], f)

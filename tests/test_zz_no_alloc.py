@@ -82,6 +82,82 @@ def test_noalloc_step_under_the_callers_stream_capture(pkg, hip):
     ref.close()
 
 
+def test_noalloc_step_hands_the_kernels_the_static_scratch(pkg, hip, monkeypatch):
+    """The sink row is write-only, so equal results cannot tell WHICH row the kernels were handed.
+    fluid_debug_sink can: canary both rows, step, and see which one was written.  fluid_step_noalloc
+    must leave the context's own hipMalloc'ed row untouched and write the GPU's static scratch;
+    fluid_step the other way round.  600^2 with the pipeline forced: strips leave the domain on the
+    right, so sink columns are certainly written."""
+    monkeypatch.setenv("FLUID_TILE", "0")
+    for n, J in ((600, 10), (2048, 16)):
+        sim = pkg.FluidSim(n, lib=hip, pressure_iters=J)
+        sim.add_source(0.5, 0.5, 10.0, -5.0)
+        for which in (0, 1):
+            sim.debug_sink(which, fill=True)
+            assert sim.debug_sink(which, fill=False) == 0
+        sim.step_noalloc(2)
+        assert sim.debug_sink(0, fill=False) == 0, "fluid_step_noalloc wrote the context's own sink row"
+        assert sim.debug_sink(1, fill=False) > 0, "fluid_step_noalloc did not write the static scratch"
+        sim.debug_sink(1, fill=True)
+        sim.step(2)
+        assert sim.debug_sink(1, fill=False) == 0, "fluid_step wrote the static scratch"
+        assert sim.debug_sink(0, fill=False) > 0, "fluid_step did not write the context's own sink row"
+        sim.close()
+
+
+FRESH = r"""
+import sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch
+import fluid_amd_loader
+pkg = fluid_amd_loader.load()
+n, J = %(n)d, %(J)d
+# the captured context is the FIRST thing this process launches: first use of the code objects (and
+# the > 64 KB LDS attribute of the tiles) happens inside the caller's global-mode capture
+sim = pkg.FluidSim(n, pressure_iters=J)
+stream = torch.cuda.Stream()
+sim.set_stream(stream.cuda_stream)
+graph = torch.cuda.CUDAGraph()
+with torch.cuda.stream(stream):
+    graph.capture_begin()
+    sim.step_noalloc(2)
+    graph.capture_end()
+for _ in range(2):
+    graph.replay()
+torch.cuda.synchronize()
+got = [sim.read(f) for f in range(4)]
+ref = pkg.FluidSim(n, pressure_iters=J)
+ref.step(4)
+for f in range(4):
+    assert np.array_equal(got[f].view(np.uint32), ref.read(f).view(np.uint32)), f
+# a state that is not all zeros, through the same replayed graph
+for s in (sim, ref):
+    s.add_source(0.4, 0.6, 20.0, -10.0)
+graph.replay()
+torch.cuda.synchronize()
+ref.step(2)
+for f in range(4):
+    a, b = sim.read(f), ref.read(f)
+    assert float(np.abs(b).max()) > 0 and np.array_equal(a.view(np.uint32), b.view(np.uint32)), f
+print("fresh capture ok")
+"""
+
+
+@pytest.mark.parametrize("n,J,tile", [(1536, 20, "0"), (512, 10, "1")])
+def test_noalloc_capture_as_the_first_launch_of_a_fresh_process(n, J, tile):
+    """in the test above `ref` has run every kernel before the capture starts.  Here a new
+    process captures fluid_step_noalloc before anything else has launched, on the pipeline path and
+    on the LDS-tile path."""
+    import os
+    import subprocess
+    import sys
+    from util import ROOT
+    env = dict(os.environ, FLUID_TILE=tile)
+    r = subprocess.run([sys.executable, "-c", FRESH % {"root": ROOT, "n": n, "J": J}], env=env,
+                       capture_output=True, text=True, timeout=110)
+    assert r.returncode == 0 and "fresh capture ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_noalloc_step_rejects_what_it_cannot_serve(pkg, hip):
     slab = pkg.FluidSim(512, lib=hip, slab_rank=1, slab_count=4)
     with pytest.raises(pkg.FluidError) as ei:
