@@ -172,6 +172,7 @@ inline size_t cells_local(const fluid_ctx *c) { return (size_t)c->g.L * c->g.n; 
 inline size_t cells_owned(const fluid_ctx *c) { return (size_t)c->rows * c->g.n; }
 inline int state_of(const fluid_ctx *c) { return c->vin | (c->din << 1) | (c->pin << 2); }
 inline void set_state(fluid_ctx *c, int s) { c->vin = s & 1; c->din = (s >> 1) & 1; c->pin = (s >> 2) & 1; }
+inline int st_delta(int before, int after) { return (before ^ after) & 7; }  // which ping-pong indices a batch of steps flips
 
 void drop_graphs(fluid_ctx *c) {
   for (auto *m : {&c->graphs, &c->comm_graphs}) {
@@ -693,7 +694,7 @@ extern "C" {
 // inner slabs (fluid_params.inner_slabs >= 2): the whole-domain entry points of such a context
 static int inner_reset(fluid_ctx *P);
 static int inner_add_source(fluid_ctx *P, float sx, float sy, float fx, float fy, const float rgba[4]);
-static int inner_steps(fluid_ctx *P, int nsteps);
+static int inner_steps(fluid_ctx *P, int nsteps, bool launch);
 static int inner_read(fluid_ctx *P, int field, void *dst, size_t dst_bytes);
 static int inner_write(fluid_ctx *P, int field, const void *src, size_t src_bytes);
 static int inner_sync(fluid_ctx *P);
@@ -963,7 +964,7 @@ static int run_comm_steps(fluid_ctx *c, int nsteps);
 
 int fluid_step(fluid_ctx *c, int nsteps) {
   if (!c || nsteps < 0) return FLUID_E_INVALID;
-  if (is_inner(c)) return inner_steps(c, nsteps);
+  if (is_inner(c)) return inner_steps(c, nsteps, true);
   if (c->slab && c->has_comm) {  // the library exchanges the halos itself (fluid_comm_attach*)
     HIPCHK(c, hipSetDevice(c->prm.device));
     return run_comm_steps(c, nsteps);
@@ -1155,7 +1156,7 @@ const char *fluid_last_error(const fluid_ctx *c) { return c ? c->err : ""; }
 
 int fluid_prepare_steps(fluid_ctx *c, int nsteps) {
   if (!c || nsteps < 0) return FLUID_E_INVALID;
-  if (is_inner(c)) return FLUID_OK;  // inner slabs enqueue their launches directly: nothing to build
+  if (is_inner(c)) return inner_steps(c, nsteps, false);
   if (c->slab && nsteps > 1) return FLUID_E_UNSUPPORTED;
   if (c->groups > 1 && nsteps > 0) return FLUID_E_UNSUPPORTED;
   HIPCHK(c, hipSetDevice(c->prm.device));
@@ -1619,6 +1620,13 @@ int fluid_comm_selftest_rccl(int device, size_t bytes, int use_graph, char *msg,
 int fluid_comm_info(const fluid_ctx *c, fluid_comm_stats *out) {
   if (!c || !out) return FLUID_E_INVALID;
   memset(out, 0, sizeof *out);
+  if (is_inner(c)) {  // no transport: the slabs' halos are device copies; what it reports is the graph path
+    out->graph = c->comm_graph && !(c->prm.flags & FLUID_FLAG_NO_GRAPH);
+    out->graphs_built = (int)c->graphs.size();
+    snprintf(out->transport, sizeof out->transport, "inner");
+    snprintf(out->note, sizeof out->note, "%s", c->comm_note);
+    return FLUID_OK;
+  }
   out->attached = c->has_comm;
   out->capturable = c->has_comm && c->tr.capturable;
   out->graph = c->has_comm && c->comm_graph && c->tr.capturable && !(c->prm.flags & FLUID_FLAG_NO_GRAPH);
@@ -1684,6 +1692,21 @@ static int inner_init(fluid_ctx **out, const fluid_params &prm) {
     HIPCHK(P, hipSetDevice(prm.device));
     HIPCHK(P, hipStreamCreateWithFlags(&P->own_stream, hipStreamNonBlocking));
     P->stream = P->own_stream;
+    P->graph_steps = env_int("FLUID_GRAPH_STEPS", 16);
+    if (P->graph_steps < 1) P->graph_steps = 1;
+    P->comm_graph = env_int("FLUID_INNER_GRAPH", 1) != 0;  // whole steps of all slabs as one hipGraph (inner_steps)
+    {
+      // hipStreamEndCapture of this fork (G sibling streams of real launches) segfaults in the HIP
+      // runtime 7.0.51831 that PyTorch-ROCm 2.10 bundles and loads first in a Python process, and
+      // works in ROCm 7.2's own (7.2.26015) — same library, same calls (tools/inner_dbg.py with and
+      // without torch, gpurun_out/r3_inner_dbg*.log).  Older runtimes get direct launches.
+      int rv = 0;
+      if (hipRuntimeGetVersion(&rv) != hipSuccess) { (void)hipGetLastError(); rv = 0; }
+      if (P->comm_graph && rv < 70200000 && !env_int("FLUID_INNER_GRAPH_FORCE", 0)) {
+        P->comm_graph = false;
+        snprintf(P->comm_note, sizeof P->comm_note, "inner slabs: direct launches (HIP runtime %d < 7.2 crashes in hipStreamEndCapture)", rv);
+      }
+    }
     HIPCHK(P, hipEventCreateWithFlags(&P->ev_fork, hipEventDisableTiming));
     for (int r = 0; r < G; ++r) {
       fluid_params sp = prm;
@@ -1771,14 +1794,19 @@ static int inner_wait_halos(fluid_ctx *P, size_t i) {
 }
 
 // nsteps steps of every slab, enqueue only (between inner_fork and inner_join)
-static int inner_enqueue(fluid_ctx *P, int nsteps) {
+// halos_joined: the pushes for the current state are not only enqueued but already joined into this
+// context's stream (every inner_* call ends with inner_join), so the fork orders the first step
+// after them and its wait on the neighbours' ev_halo is skipped — under stream capture that wait
+// would name events recorded outside the capture, which the runtime refuses ("dependency created on
+// uncaptured work in another stream").
+static int inner_enqueue(fluid_ctx *P, int nsteps, bool halos_joined = false) {
   const size_t G = P->subs.size();
   int rc;
   for (int k = 0; k < nsteps; ++k) {
     if ((rc = inner_refresh(P))) return rc;
     for (size_t i = 0; i < G; ++i) {
       fluid_ctx *s = P->subs[i];
-      if ((rc = inner_wait_halos(P, i))) return rc;
+      if (!(halos_joined && k == 0) && (rc = inner_wait_halos(P, i))) return rc;
       // enq_velocity_head in two pieces, with the event between them
       const int m_diff = s->prm.pressure_iters + 1;
       enq_advect_velocity(s, m_diff + s->prm.diffusion_iters);
@@ -1799,23 +1827,84 @@ static int inner_enqueue(fluid_ctx *P, int nsteps) {
   return FLUID_OK;
 }
 
-// Direct launches: capturing the slabs' streams into one hipGraph (one branch per stream, events
-// waited for by several streams) crashed hipStreamEndCapture on ROCm 7.2 (host segfault, from either
-// origin stream) and was dropped; a step costs the host 50-90 us to enqueue for two slabs, which the
-// sizes this is for (>= 2048^2: >= 190 us per step) hide.
-static int inner_steps(fluid_ctx *P, int nsteps) {
+// Whole steps of every slab as ONE hipGraph per batch (power-of-two batches as in run_steps): the
+// origin is this context's stream, the fork pulls the G sibling streams into the capture, the join
+// brings them back.  A graph begins with the halo pushes of its start state enqueued AND joined into
+// the origin (so nothing inside it waits for an event recorded outside it, see inner_enqueue) and
+// ends the same way.  Round 2 recorded a host segfault in hipStreamEndCapture for a first attempt at
+// this; tools/ubench/capture_fork.hip replays the stream/event shape with empty kernels: forks,
+// sibling-to-sibling waits and events re-recorded across 16 steps all capture and replay, and a wait
+// on an event recorded outside the capture is REFUSED by hipStreamWaitEvent (that attempt had such
+// waits: the previous call's pushes).  launch == false: only build the graphs.
+static int inner_direct(fluid_ctx *P, int nsteps) {
+  int rc = inner_fork(P);
+  if (rc) return rc;
+  if ((rc = inner_enqueue(P, nsteps))) return rc;
+  return inner_join(P);
+}
+
+static int inner_steps(fluid_ctx *P, int nsteps, bool launch) {
   // Under the caller's stream capture (fluid_set_stream + hipStreamBeginCapture) the fork below would
-  // pull the G sibling streams, with their waits on each other's events, into that capture: the shape
-  // that crashed the runtime (above).  Refused, not attempted.
+  // pull the G sibling streams into that capture, on top of events recorded outside it.  Refused, not
+  // attempted.
   HIPCHK(P, hipSetDevice(P->prm.device));
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(P->stream, &cap) != hipSuccess) (void)hipGetLastError();
   if (cap != hipStreamCaptureStatusNone)
     return fail(P, FLUID_E_UNSUPPORTED, "fluid_step on an inner_slabs context cannot run under stream capture");
-  int rc = inner_fork(P);
-  if (rc) return rc;
-  if ((rc = inner_enqueue(P, nsteps))) return rc;
-  return inner_join(P);
+  const bool graph = P->comm_graph && !(P->prm.flags & FLUID_FLAG_NO_GRAPH);
+  if (!graph) return launch ? inner_direct(P, nsteps) : FLUID_OK;
+  const size_t G = P->subs.size();
+  std::vector<int> st0(G), first(G);
+  for (size_t i = 0; i < G; ++i) first[i] = state_of(P->subs[i]);
+  for (int s = 0; s < nsteps;) {
+    int rc;
+    if (!P->inner_posted) {  // eagerly: pushes for the current state, joined into this stream
+      if ((rc = inner_fork(P)) || (rc = inner_refresh(P)) || (rc = inner_join(P))) return rc;
+    }
+    int batch = 1;
+    while (batch * 2 <= P->graph_steps && batch * 2 <= nsteps - s) batch *= 2;
+    const int key = state_of(P->subs[0]) | (batch << 8);  // the slabs' ping-pong indices move together
+    auto it = P->graphs.find(key);
+    if (it == P->graphs.end()) {
+      GraphEntry ge;
+      for (size_t i = 0; i < G; ++i) st0[i] = state_of(P->subs[i]);
+      const bool trace = env_int("FLUID_TRACE", 0) != 0;
+#define TR(msg) do { if (trace) { fprintf(stderr, "[inner graph] %s\n", msg); fflush(stderr); } } while (0)
+      if (trace) { int rv = 0; (void)hipRuntimeGetVersion(&rv); fprintf(stderr, "[inner graph] hip runtime version %d\n", rv); }
+      TR("begin capture");
+      HIPCHK(P, hipStreamBeginCapture(P->stream, hipStreamCaptureModeRelaxed));
+      rc = inner_fork(P);
+      TR("forked");
+      if (!rc) rc = inner_enqueue(P, batch, true);
+      TR("enqueued");
+      if (!rc) rc = inner_join(P);
+      TR("joined");
+      const hipError_t e = hipStreamEndCapture(P->stream, &ge.graph);
+      TR("capture ended");
+      ge.next_state = state_of(P->subs[0]);
+      for (size_t i = 0; i < G; ++i) { set_state(P->subs[i], st0[i]); P->subs[i]->enq_rc = 0; }
+      hipError_t ei = hipSuccess;
+      if (!rc && e == hipSuccess) ei = hipGraphInstantiate(&ge.exec, ge.graph, nullptr, nullptr, 0);
+      TR("instantiated");
+      if (rc || e != hipSuccess || ei != hipSuccess) {  // nothing of it has run: direct launches from now on
+        snprintf(P->comm_note, sizeof P->comm_note, "inner slabs: graph capture given up (%s)",
+                 rc ? "enqueue" : e != hipSuccess ? hipGetErrorString(e) : hipGetErrorString(ei));
+        if (ge.graph) (void)hipGraphDestroy(ge.graph);
+        (void)hipGetLastError();
+        P->comm_graph = false;
+        return launch ? inner_direct(P, nsteps - s) : FLUID_OK;
+      }
+      it = P->graphs.emplace(key, ge).first;
+    }
+    if (launch) HIPCHK(P, hipGraphLaunch(it->second.exec, P->stream));
+    // the ping-pong indices `batch` steps flip, for every slab alike (undone below when only building)
+    for (size_t i = 0; i < G; ++i) set_state(P->subs[i], state_of(P->subs[i]) ^ st_delta(key & 7, it->second.next_state));
+    s += batch;
+  }
+  if (!launch)
+    for (size_t i = 0; i < G; ++i) set_state(P->subs[i], first[i]);
+  return FLUID_OK;
 }
 
 static int inner_reset(fluid_ctx *P) {
@@ -1907,8 +1996,10 @@ static int inner_time_steps(fluid_ctx *P, int nsteps, float *ms_out) {
   HIPCHK(P, hipEventCreate(&e0));
   HIPCHK(P, hipEventCreate(&e1));
   const int rc = [&]() -> int {
+    int r = inner_steps(P, nsteps, false);  // graphs built outside the timed region
+    if (r) return r;
     HIPCHK(P, hipEventRecord(e0, P->stream));
-    const int r = inner_steps(P, nsteps);
+    r = inner_steps(P, nsteps, true);
     if (r) return r;
     HIPCHK(P, hipEventRecord(e1, P->stream));
     HIPCHK(P, hipEventSynchronize(e1));

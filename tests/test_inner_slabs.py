@@ -189,3 +189,53 @@ def test_inner_slabs_refuse_the_callers_stream_capture(pkg, hip):
     a, b = read_all(plain, pkg), read_all(inner, pkg)
     for f in FIELDS:
         assert_bit_equal(b[f], a[f], f)
+
+
+GRAPH_SCRIPT = r"""
+import sys
+sys.modules["torch"] = None      # capi.py then loads ROCm's own HIP runtime instead of the one torch bundles
+sys.path.insert(0, %(root)r)
+import numpy as np
+import fluid_amd_loader
+pkg = fluid_amd_loader.load()
+for n, J, G in ((512, 10, 2), (1536, 25, 3), (2048, 40, 2)):
+    plain = pkg.FluidSim(n, pressure_iters=J)
+    inner = pkg.FluidSim(n, pressure_iters=J, inner_slabs=G)
+    ss_a, ss_b = pkg.SplatStream(), pkg.SplatStream()
+    for steps in (1, 2, 3, 21, 16):
+        plain.add_source(*ss_a.splat())
+        inner.add_source(*ss_b.splat())
+        plain.step(steps)
+        inner.step(steps)
+        inner.step(1)          # no splat in between: the halos posted by the graph are reused
+        plain.step(1)
+        for f in range(4):
+            a, b = plain.read(f), inner.read(f)
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (n, G, steps, f)
+    info = inner.comm_info()
+    print(n, G, info["graph"], info["graphs_built"], info["note"])
+    assert info["graph"] and info["graphs_built"] >= 4 and not info["note"], info
+print("inner graphs ok")
+"""
+
+
+def test_inner_slabs_as_one_hipgraph_under_the_system_runtime(pkg, hip):
+    """VERDICT r2 item 5.  Whole steps of all slabs captured as ONE hipGraph (origin stream forks the
+    G sibling streams, siblings wait on each other's events, everything joins back) replay with the
+    bits of the one-stream context — under ROCm 7.2's HIP runtime.  The runtime PyTorch bundles
+    (7.0.51831), which this pytest process has loaded, segfaults in hipStreamEndCapture on that shape,
+    so there the library keeps to direct launches and says so; the graph path is therefore tested in
+    a child process that never imports torch."""
+    import os
+    import subprocess
+    import sys
+    from util import ROOT
+    here = pkg.FluidSim(512, lib=hip, inner_slabs=2)
+    info = here.comm_info()
+    import torch
+    if torch.version.hip and torch.version.hip.startswith("7.0"):
+        assert not info["graph"] and "direct launches" in info["note"], info
+    here.close()
+    r = subprocess.run([sys.executable, "-c", GRAPH_SCRIPT % {"root": ROOT}], capture_output=True, text=True, timeout=110,
+                       env=dict(os.environ))
+    assert r.returncode == 0 and "inner graphs ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -9,6 +9,8 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+if os.environ.get("FLUID_NO_TORCH"):
+    sys.modules["torch"] = None   # the system HIP runtime (7.2) instead of the one torch bundles (7.0)
 import fluid_amd_loader  # noqa: E402
 
 pkg = fluid_amd_loader.load()
