@@ -92,8 +92,6 @@ struct fluid_ctx {
   // temporal-blocking plan (fused path): sweeps per launch, columns per lane, target waves
   int tb_kj = 10, tb_kd = 5, tb_cj = 2, tb_cd = 2, tb_waves = 8192, tb_minchunk = 4;
   float tb_rounds = 0.f;  // > 0: size the temporally blocked launches to this many resident rounds of workgroups (tb_chunk)
-  int ws_k = 0;       // > 0: pressure launches of this many sweeps run the wave-split kernel (fluid_kernels_ws.hip)
-  int ws_blocks = 0;  // ... sized to this many workgroups (0 = one resident round)
   int tb_waves_d = 0;  // target waves of the diffusion launches (0 = tb_waves): they hold more registers, so fewer are resident
   bool tile_div = true;    // tile path: the last diffusion launch also writes the divergence (FLUID_TILE_DIV)
   bool div_ready = false;  // ... and did, for the projection about to be enqueued
@@ -472,19 +470,6 @@ void enq_pressure_group(fluid_ctx *c, int g) {
   }
   if (tb) {
     while (left > 0) {
-      if (c->ws_k > 0 && left >= c->ws_k && ws_supported(c->g.n)) {
-        const int k = c->ws_k;
-        ProfScope p(c, K_JACOBI_WS, 12.0 * k * cells, 12.0 * cells);
-        const Range r = widened(c, 1 + left - k);
-        const int target = c->ws_blocks > 0 ? c->ws_blocks : ws_resident_blocks(k);
-        int chunks = (target > 0 ? target : 1024) / ws_strips_of(c->g.n, k);
-        if (chunks < 1) chunks = 1;
-        const int chunk = (r.r1 - r.r0 + chunks - 1) / chunks;
-        LAUNCH(c, launch_jacobi_ws(c->stream, c->g, r.r0, r.r1, k, chunk, c->prs[c->pin], c->div, c->prs[c->pin ^ 1], c->dump));
-        c->pin ^= 1;
-        left -= k;
-        continue;
-      }
       const int k = next_pass(c, left, false);
       ProfScope p(c, K_JACOBI_TB, 12.0 * k * cells, 12.0 * cells);
       const Range r = widened(c, 1 + left - k);
@@ -868,15 +853,11 @@ static int init_ctx(fluid_ctx **out, const fluid_params *p, int inner_of) {
   if (env_int("FLUID_TB_WAVES", 0) > 0) c->tb_rounds = 0.f;  // an explicit wave target wins over the table's rounds
   c->tb_rounds = env_int("FLUID_TB_ROUNDS_PCT", (int)(c->tb_rounds * 100.f + 0.5f)) / 100.f;
   c->tb_minchunk = env_int("FLUID_TB_MINCHUNK", c->tb_minchunk);
-  c->ws_k = env_int("FLUID_WS", c->ws_k);
-  if (!ws_has_k(c->ws_k)) c->ws_k = 0;
-  c->ws_blocks = env_int("FLUID_WS_BLOCKS", 0);
   c->alpha = 1.0f / (prm.viscosity * prm.dt);  // kernel.cu:182, fp32 at run time
   c->beta = 1.0f / (4.0f + c->alpha);          // kernel.cu:183
   int rc = [&]() -> int {
     HIPCHK(c, hipSetDevice(prm.device));
     fill_pass_tables(c);  // asks the runtime for occupancies: on this context's device, hence after hipSetDevice
-    if (c->ws_k > 0) (void)ws_resident_blocks(c->ws_k);
     // this device's copy of the static scratch (fluid_step_noalloc).  A failed lookup (or a device
     // ordinal beyond the table) only disables that one entry point: it reports the missing address itself.
     (void)scratch_setup(prm.device);

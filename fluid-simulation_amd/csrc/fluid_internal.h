@@ -32,7 +32,6 @@ enum KernelId {
   K_DIFFUSE_TILE,         // LDS-tiled sweeps for small grids (fluid_kernels_tile.hip)
   K_JACOBI_TILE,
   K_JACOBI_DIV_TILE,
-  K_JACOBI_WS,  // temporally blocked Jacobi, levels split over the waves of a workgroup (fluid_kernels_ws.hip)
   K_COUNT
 };
 extern const char *const kKernelNames[K_COUNT];
@@ -80,16 +79,6 @@ bool launch_jacobi_div_tb(hipStream_t s, Geom g, int r0, int r1, int k, int cols
                           const float2 *vel, float *div_out, float *pout, void *dump);
 bool launch_diffuse_tb(hipStream_t s, Geom g, int r0, int r1, int k, int cols, int chunk,
                        float alpha, float beta, const float2 *vin, float2 *vout, void *dump);
-
-// ---- temporally blocked Jacobi with the levels split over a workgroup's waves (fluid_kernels_ws.hip) ----
-// k sweeps per launch (ws_has_k), 4 columns per lane, one 256-column strip per workgroup of 4 waves;
-// chunk = rows a workgroup streams.  false: shape or sweep count not in this build.
-bool ws_has_k(int k);
-bool ws_supported(int n);
-int ws_strips_of(int n, int k);
-int ws_resident_blocks(int k);
-bool launch_jacobi_ws(hipStream_t s, Geom g, int r0, int r1, int k, int chunk, const float *pin, const float *div,
-                      float *pout, void *dump);
 
 // ---- LDS-tiled sweeps for small grids (fluid_kernels_tile.hip) ---------------
 // k sweeps per launch on local rows [r0, r1); false when k is not instantiated.

@@ -1,4 +1,6 @@
-// fluid_kernels_ws.hip — pressureJacobi sweeps (/root/reference/FluidSimulation/kernel.cu:291-324,
+// wave_split_jacobi.hip (round 3 experiment, NOT built into libfluid_hip.so; it was
+// csrc/fluid_kernels_ws.hip in the commit before this file moved here, wired in as FLUID_WS=K;
+// measurements: profiles/r03/r3_ws*.log) — pressureJacobi sweeps (/root/reference/FluidSimulation/kernel.cu:291-324,
 // loop :620-641), temporally blocked with the K levels SPLIT OVER THE WAVES OF A WORKGROUP.
 //
 // fluid_kernels_tb.hip keeps all K levels x 3 rows of a strip in ONE wave's registers: 108-160
