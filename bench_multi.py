@@ -95,13 +95,21 @@ def supervise_rank(argv):
     return 1
 
 
-def _checksums(pkg, sim):
-    import numpy as np
-    return [int(sim.read(f).view(np.uint32).sum(dtype=np.uint64))
-            for f in (pkg.FIELD_VELOCITY, pkg.FIELD_DENSITY, pkg.FIELD_PRESSURE)]
+def _checksums(pkg, sim, row0=0, rows=0):
+    """fluid_checksum of the three state fields: computed on the device, 8 bytes each cross the bus
+    (round 2 read the rows through the host: 7.4 GB per rank at 16384^2)."""
+    return [sim.checksum(f, row0, rows) for f in (pkg.FIELD_VELOCITY, pkg.FIELD_DENSITY, pkg.FIELD_PRESSURE)]
 
 
-VERIFY_STEPS = 3
+VERIFY_STEPS = 3          # 2 + 1: small batches, and the eager first exchange
+VERIFY_GRAPH_STEPS = 16   # then one full batch: in "rccl-graph" mode a replayed 16-step hipGraph
+
+
+def _null_transport(pkg, capturable):
+    """A transport whose calls do nothing: what a rank spends per step apart from the messages."""
+    cb = (pkg.capi.TRANSPORT_GROUP_START(lambda u: 0), pkg.capi.TRANSPORT_SEND(lambda u, p, b, r, st: 0),
+          pkg.capi.TRANSPORT_RECV(lambda u, p, b, r, st: 0), pkg.capi.TRANSPORT_GROUP_END(lambda u, st: 0))
+    return pkg.FluidTransport(None, *cb, int(capturable)), cb
 
 
 def run_multi(pkg, args, n, D, J, flags):
@@ -167,13 +175,11 @@ def run_multi(pkg, args, n, D, J, flags):
     # The truth: the whole domain on this rank's own GPU, VERIFY_STEPS steps from the seeded splats.
     whole = pkg.FluidSim(n, device=local, diffusion_iters=D, pressure_iters=J, flags=flags)
     seeded_warm_state(pkg, whole)
-    whole.step(VERIFY_STEPS)
     plan = pkg.FluidLib().slab_plan(n, rank, world, diffusion_iters=D, pressure_iters=J, pressure_groups=groups)
-    truth = []
-    for f in (pkg.FIELD_VELOCITY, pkg.FIELD_DENSITY, pkg.FIELD_PRESSURE):
-        a = whole.read(f)
-        truth.append(int(a[plan["row0"]:plan["row0"] + plan["rows"]].view(np.uint32).sum(dtype=np.uint64)))
-        del a
+    whole.step(VERIFY_STEPS)
+    truth = _checksums(pkg, whole, plan["row0"], plan["rows"])
+    whole.step(VERIFY_GRAPH_STEPS)
+    truth_batch = _checksums(pkg, whole, plan["row0"], plan["rows"])
     whole.close()
 
     modes = os.environ.get("FLUID_BENCH_MODES", default_modes()).split(",") if world > 1 else ["torch"]
@@ -195,11 +201,19 @@ def run_multi(pkg, args, n, D, J, flags):
             seeded_warm_state(pkg, s_)
             s_.step(VERIFY_STEPS)
             s_.sync()
-            ok = _checksums(pkg, s_) == truth
+            ok = _checksums(pkg, s_.sim) == truth
             if not ok:
                 note = "slab rows differ from the whole-domain run"
+            if ok:   # ... and after one more full batch of steps (a replayed hipGraph in "rccl-graph" mode)
+                s_.step(VERIFY_GRAPH_STEPS)
+                s_.sync()
+                ok = _checksums(pkg, s_.sim) == truth_batch
+                if not ok:
+                    note = f"slab rows differ from the whole-domain run after a batch of {VERIFY_GRAPH_STEPS} more steps"
             if ok and m == "rccl-graph" and not s_.sim.comm_info()["graph"]:
                 ok, note = False, "graph capture refused: " + s_.sim.comm_info()["note"]
+            if ok and m in ("rccl-graph", "rccl") and s_.sim.comm_info()["ranks"] != world:
+                ok, note = False, f"RCCL reports {s_.sim.comm_info()['ranks']} ranks, not {world}"
         except Exception as e:   # noqa: BLE001 - any failure means: next mode
             note = f"{type(e).__name__}: {e}"
         ok = all_min(ok)
@@ -244,12 +258,53 @@ def run_multi(pkg, args, n, D, J, flags):
     sim.step(args.steps)
     sim.sync()
     torch.cuda.synchronize()
+    mine = time.perf_counter() - t0   # this rank's own GPU is done (the barrier below adds the others' lag)
     dist.barrier()
     wall = all_max(time.perf_counter() - t0)
     moved = sim.bytes_moved - moved0   # sent in the timed region only
+    per_rank = [None] * world
+    dist.all_gather_object(per_rank, round(mine / args.steps * 1e3, 5))
 
     diag = sim.diagnostics()   # slab reductions + all-reduce, after the timed region
     comm = sim.sim.comm_info() if sim.in_library else None
+
+    # Where the time went, on the same slab in the same run: the steps again with a transport whose
+    # calls do nothing (same launches, same graphs or direct enqueueing, no message), so
+    # exposed communication = timed - compute-only; and one step kernel by kernel for the roofline of
+    # the slab's dominant launch.  The fields are garbage afterwards (stale halos): nothing reads them.
+    compute_only, per_rank_compute, roofline, kernels = None, None, None, None
+    if sim.in_library:
+        try:
+            sim.sim.comm_detach()
+            tr, keep = _null_transport(pkg, capturable=(mode == "rccl-graph"))
+            sim.sim.comm_attach(tr)
+            k = max(2, min(args.steps, 20))
+            sim.sim.step(max(args.warmup, 2))
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            sim.sim.step(k)
+            torch.cuda.synchronize()
+            mine_c = (time.perf_counter() - t1) / k * 1e3
+            sim.sim.comm_detach()
+            stats = [st for st in sim.sim.profile_steps(1) if st["launches"]]
+            kernels = {st["name"]: {"launches": st["launches"], "ms_per_launch": round(st["total_ms"] / st["launches"], 5)}
+                       for st in stats}
+            dom = max(stats, key=lambda st: st["total_ms"])
+            avg = dom["total_ms"] / dom["launches"]
+            roofline = {"bound": "hbm", "kernel": dom["name"], "rank": rank, "launches_per_step": dom["launches"],
+                        "avg_launch_ms": round(avg, 5),
+                        "achieved": round(dom["alg_bytes"] / (avg * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": round(dom["alg_bytes"] / (avg * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                        "moved_bytes_per_launch": dom["moved_bytes"],
+                        "frac_moved": round(dom["moved_bytes"] / (avg * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                        "traffic": None, "timing": "HIP events on the slab context's stream, one step, direct launches"}
+        except pkg.FluidError as e:   # e.g. FLUID_E_HALO from the stale halos: the line still comes out
+            mine_c = None
+            roofline = {"error": str(e)}
+        per_rank_compute = [None] * world
+        dist.all_gather_object(per_rank_compute, None if mine_c is None else round(mine_c, 5))
+        if all(v is not None for v in per_rank_compute):
+            compute_only = max(per_rank_compute)
     if rank == 0:
         t_step = wall / args.steps
         bpc = pkg.alg_bytes_per_cell(D, J)
@@ -278,6 +333,14 @@ def run_multi(pkg, args, n, D, J, flags):
             "transport": carrier, "exchange_mode": mode, "modes_tried": tried,
             "attempt": attempt,
             "halo_bytes_per_step_per_rank": moved // max(args.steps, 1),
+            # what RCCL itself says (ncclCommCount through fluid_comm_info); None: not an RCCL mode
+            "rccl_ranks": comm["ranks"] if comm and mode in ("rccl-graph", "rccl") else None,
+            "per_rank_ms_per_step": per_rank,
+            "compute_only_ms_per_step": None if compute_only is None else round(compute_only, 5),
+            "compute_only_per_rank_ms_per_step": per_rank_compute,
+            "exposed_comm_ms_per_step": None if compute_only is None else round(t_step * 1e3 - compute_only, 5),
+            "roofline": roofline, "slab_kernels_rank0": kernels,
+            "verified_after_steps": [VERIFY_STEPS, VERIFY_STEPS + VERIFY_GRAPH_STEPS],
             # the timed configuration reproduced the whole-domain run (every rank's own GPU, 3 steps)
             # bit for bit on every rank's rows before it was timed
             "slab_matches_whole_domain": True, "overlap_matches_plain_exchange": True,

@@ -22,7 +22,7 @@ _FIELD_COMPONENTS = {FIELD_VELOCITY: 2, FIELD_DENSITY: 4, FIELD_PRESSURE: 1, FIE
 ABI_SYMBOLS = [
     "fluid_default_params", "fluid_init", "fluid_destroy", "fluid_reset", "fluid_add_source",
     "fluid_step", "fluid_prepare_steps", "fluid_step_noalloc", "fluid_debug_sink", "fluid_advect_velocity", "fluid_diffuse", "fluid_vorticity", "fluid_project",
-    "fluid_advect_density", "fluid_read", "fluid_write", "fluid_sync", "fluid_diagnostics", "fluid_geometry",
+    "fluid_advect_density", "fluid_read", "fluid_write", "fluid_sync", "fluid_diagnostics", "fluid_checksum", "fluid_geometry",
     "fluid_strerror", "fluid_last_error", "fluid_time_steps", "fluid_profile_steps",
     "fluid_stream", "fluid_set_stream",
     "fluid_slab_plan", "fluid_halo_bytes", "fluid_halo_pack", "fluid_halo_unpack",
@@ -88,12 +88,12 @@ class FluidTransport(C.Structure):
 class FluidCommStats(C.Structure):
     _fields_ = [("attached", C.c_int), ("capturable", C.c_int), ("graph", C.c_int), ("graphs_built", C.c_int),
                 ("exchanges", C.c_longlong), ("bytes_sent", C.c_longlong), ("transport", C.c_char * 16),
-                ("note", C.c_char * 160)]
+                ("note", C.c_char * 160), ("ranks", C.c_int), ("reserved", C.c_int)]
 
     def as_dict(self):
         return {"attached": bool(self.attached), "capturable": bool(self.capturable), "graph": bool(self.graph),
                 "graphs_built": self.graphs_built, "exchanges": self.exchanges, "bytes_sent": self.bytes_sent,
-                "transport": self.transport.decode(), "note": self.note.decode()}
+                "transport": self.transport.decode(), "note": self.note.decode(), "ranks": self.ranks}
 
 
 class FluidError(RuntimeError):
@@ -153,6 +153,7 @@ class FluidLib:
         sig("fluid_read", C.c_int, P, C.c_int, P, C.c_size_t)
         sig("fluid_write", C.c_int, P, C.c_int, P, C.c_size_t)
         sig("fluid_diagnostics", C.c_int, P, C.POINTER(FluidDiag), required=False)
+        sig("fluid_checksum", C.c_int, P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_ulonglong), required=False)
         sig("fluid_geometry", C.c_int, P, C.POINTER(C.c_int), C.POINTER(C.c_int),
             C.POINTER(C.c_int))
         sig("fluid_strerror", C.c_char_p, C.c_int)
@@ -363,6 +364,13 @@ class FluidSim:
         d = FluidDiag()
         self._chk(self.lib.dll.fluid_diagnostics(self._h, C.byref(d)), "fluid_diagnostics")
         return d.as_dict()
+
+    def checksum(self, field: int, row0: int = 0, rows: int = 0) -> int:
+        """fluid_checksum: sum of the 32-bit words of global rows [row0, row0 + rows) of the current
+        half of `field` modulo 2^64, computed on the device (rows = 0: all owned rows)."""
+        out = C.c_ulonglong()
+        self._chk(self.lib.dll.fluid_checksum(self._h, field, row0, rows, C.byref(out)), "fluid_checksum")
+        return out.value
 
     def read(self, field: int) -> np.ndarray:
         comps = _FIELD_COMPONENTS[field]

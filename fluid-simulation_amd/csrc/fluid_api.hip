@@ -83,6 +83,7 @@ struct fluid_ctx {
   int vin = 0, din = 0, pin = 0;  // inputVelocityBuffer / inputDensityBuffer / inputPressureBuffer
   int *halo_flag = nullptr;       // device word: advection left the stored rows
   void *dump = nullptr;           // one row (n * 16 B): sink for rows a TB wave must not store
+  unsigned long long *cksum = nullptr;  // fluid_checksum: one device word (allocated on first use)
   float *diag_partial = nullptr;  // fluid_diagnostics: per-block records + the result (allocated on first use)
   DiagResult *diag_out = nullptr;
   char *arena = nullptr;          // the seven field buffers live in one allocation (fluid_init)
@@ -930,6 +931,7 @@ void fluid_destroy(fluid_ctx *c) {
   if (c->halo_flag) (void)hipFree(c->halo_flag);
   if (c->dump) (void)hipFree(c->dump);
   if (c->diag_partial) (void)hipFree(c->diag_partial);
+  if (c->cksum) (void)hipFree(c->cksum);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -1127,6 +1129,26 @@ int fluid_diagnostics(fluid_ctx *c, fluid_diag *out) {
   out->max_jacobi_update = r.mx[4];
   out->max_abs_div_velocity = r.mx[5];
   for (int k = 0; k < 4; ++k) out->dye[k] = r.sm[k];
+  return check_halo_flag(c);
+}
+
+int fluid_checksum(fluid_ctx *c, int field, int row0, int rows, unsigned long long *out) {
+  if (!c || !out || row0 < 0 || rows < 0) return FLUID_E_INVALID;
+  NOT_ON_INNER(c, "fluid_checksum");
+  if (rows == 0) { row0 = c->row0; rows = c->rows; }
+  if (row0 < c->row0 || row0 + rows > c->row0 + c->rows) return FLUID_E_INVALID;
+  size_t elem = 0;
+  const char *src = (const char *)field_ptr(c, field, &elem);
+  if (!elem || !src) return FLUID_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->prm.device));
+  if (!c->cksum) HIPCHK(c, hipMalloc(&c->cksum, 256));
+  HIPCHK(c, hipMemsetAsync(c->cksum, 0, sizeof(unsigned long long), c->stream));
+  src += (size_t)(row0 - c->row0 + c->own_r0) * c->g.n * elem;
+  launch_checksum(c->stream, src, (size_t)rows * c->g.n * elem / 4, c->cksum);
+  int rc = check_launch(c);
+  if (rc) return rc;
+  HIPCHK(c, hipMemcpyAsync(out, c->cksum, sizeof *out, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   return check_halo_flag(c);
 }
 
@@ -1517,7 +1539,11 @@ static int comm_attach_common(fluid_ctx *c, const Transport &t) {
   c->tr = t;
   c->has_comm = true;
   c->halo_state = HALO_NONE;
-  c->comm_graph = env_int("FLUID_COMM_GRAPH", 1) != 0;
+  // Whole slab steps (both streams + the transport's calls) as hipGraphs: opt-in (FLUID_COMM_GRAPH=1)
+  // until a run with two or more RCCL ranks exists — a capture that fails is noticed and falls back,
+  // a replay that hangs or moves wrong data on real links would not be.  bench.py --gpus N
+  // asks for it explicitly, verifies a replayed batch against the whole-domain run and falls back itself.
+  c->comm_graph = env_int("FLUID_COMM_GRAPH", 0) != 0;
   c->early_advect = env_int("FLUID_SLAB_EARLY_ADVECT", 1) != 0;
   c->comm_note[0] = 0;
   return FLUID_OK;
@@ -1635,6 +1661,7 @@ int fluid_comm_info(const fluid_ctx *c, fluid_comm_stats *out) {
   out->bytes_sent = c->comm_bytes;
   snprintf(out->transport, sizeof out->transport, "%s", c->has_comm ? c->tr.name : "");
   snprintf(out->note, sizeof out->note, "%s", c->comm_note);
+  out->ranks = c->has_comm && c->tr.ranks ? c->tr.ranks(c->tr.user) : 0;
   return FLUID_OK;
 }
 

@@ -92,6 +92,11 @@ int t_recv(void *user, void *dst, size_t bytes, int peer, void *stream) {
 }
 int t_group_end(void *user, void *) { return note((RcclUser *)user, g_api.GroupEnd(), "ncclGroupEnd"); }
 const char *t_error(void *user) { return ((RcclUser *)user)->err; }
+int t_ranks(void *user) {  // ncclCommCount: what RCCL itself says, not what the caller asked for
+  int n = 0;
+  RcclUser *u = (RcclUser *)user;
+  return u->comm && g_api.CommCount(u->comm, &n) == ncclSuccess ? n : 0;
+}
 void t_destroy(void *user) {
   RcclUser *u = (RcclUser *)user;
   if (u->owned && u->comm && g_api.CommDestroy) (void)g_api.CommDestroy(u->comm);
@@ -105,6 +110,7 @@ void fill(Transport *out, RcclUser *u) {
   out->recv = t_recv;
   out->group_end = t_group_end;
   out->error = t_error;
+  out->ranks = t_ranks;
   out->destroy = t_destroy;
   out->capturable = true;  // RCCL send/recv may be issued under stream capture (graph nodes)
   out->name = "rccl";

@@ -107,6 +107,8 @@ struct DiagResult { float mx[DIAG_NMAX]; double sm[DIAG_NSUM]; };
 void launch_diagnostics(hipStream_t s, Geom g, int r0, int r1, const float2 *vel, const float4 *dens,
                         const float *p, const float *div, float *partial, DiagResult *out);
 
+void launch_checksum(hipStream_t s, const void *base, size_t words, unsigned long long *out);
+
 // ---- halo transport (fluid_comm.hip; include/fluid.h fluid_comm_*) -----------------------------
 // One exchange = group_start, then a send and a recv per neighbour and field, then group_end, all
 // on one stream; every call returns 0 or a transport error (text from `error`).  Buffers are device
@@ -118,6 +120,7 @@ struct Transport {
   int (*recv)(void *user, void *dev_dst, size_t bytes, int peer, void *hip_stream) = nullptr;
   int (*group_end)(void *user, void *hip_stream) = nullptr;
   const char *(*error)(void *user) = nullptr;   // may be null
+  int (*ranks)(void *user) = nullptr;           // may be null: ranks of the communicator behind it
   void (*destroy)(void *user) = nullptr;        // may be null
   bool capturable = false;                      // the calls may be made under stream capture
   const char *name = "";

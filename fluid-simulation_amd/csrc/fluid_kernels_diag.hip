@@ -139,7 +139,35 @@ __global__ __launch_bounds__(DIAG_THREADS) void k_diagnostics_fold(const float *
   }
 }
 
+// Sum of the 32-bit words of a block of rows, modulo 2^64: a checksum that does not leave the
+// device (bench_multi.py compares slab rows with whole-domain rows by it instead of reading 7 GB per
+// rank through the host).  Integer addition: any order gives the same value, so one 64-bit atomic per
+// workgroup is deterministic here (the float reductions above use a fixed order instead).
+__global__ __launch_bounds__(256) void k_checksum(const uint4 *__restrict__ v, size_t n16,
+                                                  const unsigned *__restrict__ tail, int ntail,
+                                                  unsigned long long *__restrict__ out) {
+  unsigned long long acc = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) {
+    const uint4 t = v[i];
+    acc += (unsigned long long)t.x + t.y + t.z + t.w;
+  }
+  if (blockIdx.x == 0 && (int)threadIdx.x < ntail) acc += tail[threadIdx.x];
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+  __shared__ unsigned long long part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+}
+
 }  // namespace
+
+// words: 32-bit words from base (16-byte aligned: whole rows of a field); *out must be zero
+void launch_checksum(hipStream_t s, const void *base, size_t words, unsigned long long *out) {
+  const size_t n16 = words / 4;
+  const int blocks = (int)((n16 + 255) / 256 < 2048 ? (n16 + 255) / 256 : 2048);
+  hipLaunchKernelGGL(k_checksum, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, s, (const uint4 *)base, n16,
+                     (const unsigned *)base + n16 * 4, (int)(words - n16 * 4), out);
+}
 
 static int diag_blocks(int rows) { return rows < DIAG_MAX_BLOCKS ? rows : DIAG_MAX_BLOCKS; }
 

@@ -228,6 +228,13 @@ typedef struct fluid_diag {
 } fluid_diag;
 FLUID_API int fluid_diagnostics(fluid_ctx *ctx, fluid_diag *out);
 
+/* Checksum of rows of the CURRENT half of `field`, computed on the device: the sum of their 32-bit
+ * words modulo 2^64 (equal checksums of equal-length blocks: almost surely equal bits).  row0 / rows
+ * are GLOBAL rows inside the rows this context owns; rows == 0: all owned rows.  No counterpart in the
+ * reference; for comparing a slab's rows with the same rows of a whole-domain context without moving
+ * gigabytes through the host (bench.py --gpus N).  Synchronises the stream. */
+FLUID_API int fluid_checksum(fluid_ctx *ctx, int field, int row0, int rows, unsigned long long *out);
+
 /* Geometry of this context: grid width (columns), first owned row, number of owned rows (for a
  * whole-domain context: 0 and the grid height ny). */
 FLUID_API int fluid_geometry(const fluid_ctx *ctx, int *n, int *row0, int *rows);
@@ -356,11 +363,15 @@ FLUID_API int fluid_halo_unpack(fluid_ctx *ctx, int dir, const void *dev_src);
  * contiguous, nothing is staged), on a second HIP stream, overlapped with compute: the last
  * kernel of a step runs on the edge rows first, the exchange for the next step is posted, and
  * the interior rows (and the interior rows of the next step's advection) are computed while the
- * messages travel.  With a capturable transport (RCCL) whole steps — both streams and the
- * send/recv calls — are captured as hipGraphs of up to 16 steps and replayed; if the capture is
- * refused the steps are enqueued directly instead (fluid_comm_info reports which).  Results are
- * bit-identical to the whole-domain run.  Contexts with pressure_groups exchange pressure rows
- * between groups as well.
+ * messages travel.  With a capturable transport (RCCL) and FLUID_COMM_GRAPH=1 in the environment
+ * whole steps — both streams and the send/recv calls — are captured as hipGraphs of up to 16 steps
+ * and replayed; if the capture is refused the steps are enqueued directly instead (fluid_comm_info
+ * reports which).  Results are bit-identical to the whole-domain run wherever that could be checked:
+ * 2-4 processes sharing one GPU with a host-staged transport, and the RCCL calls with a one-rank
+ * communicator.  NO run with two or more RCCL ranks has happened yet (the builder had one GPU at a
+ * time), so multi-GPU parity is UNPINNED on real links and graph replay is opt-in; bench.py --gpus N
+ * checks every rank's rows against a whole-domain run (fluid_checksum) before it times anything.
+ * Contexts with pressure_groups exchange pressure rows between groups as well.
  *
  * The calls are collective in the SPMD sense: every slab makes the same fluid_* calls in the same
  * order (fluid_add_source, fluid_reset and fluid_write invalidate halos already exchanged; the
@@ -399,6 +410,9 @@ typedef struct fluid_comm_stats {
   long long bytes_sent;  /* bytes sent so far                                            */
   char transport[16];    /* "rccl" / "caller"                                            */
   char note[160];        /* why graph capture was given up, if it was                    */
+  int ranks;             /* ranks of the communicator as the transport itself reports them
+                            (RCCL: ncclCommCount); 0 = the transport cannot say              */
+  int reserved;
 } fluid_comm_stats;
 FLUID_API int fluid_comm_unique_id(void *id_out, size_t id_bytes);
 FLUID_API int fluid_comm_init_rccl(fluid_ctx *ctx, const void *id, size_t id_bytes);

@@ -540,3 +540,29 @@ def test_diagnostics_full_size_properties(pkg, hip):
     for k in range(4):
         want = dens[..., k].sum(dtype=np.float64)
         assert abs(d["dye"][k] - want) <= 1e-6 * max(abs(want), 1.0)
+
+
+@pytest.mark.gpu
+def test_device_checksum_is_the_sum_of_the_words(pkg, hip):
+    """fluid_checksum (bench.py --gpus N compares slab rows with whole-domain rows by it): the sum
+    of the 32-bit words of the current half's rows modulo 2^64, for row sub-ranges, odd sizes whose
+    word count is not a multiple of four, and slab contexts."""
+    for n, ny in ((256, 0), (37, 21), (1030, 64)):
+        sim = pkg.FluidSim(n, ny=ny, lib=hip)
+        sim.add_source(0.4, 0.6, 10.0, -5.0, (1.0, 0.5, 0.25, 0.125))
+        sim.step(2)
+        rows = ny or n
+        for f in (pkg.FIELD_VELOCITY, pkg.FIELD_DENSITY, pkg.FIELD_PRESSURE, pkg.FIELD_DIVERGENCE):
+            a = sim.read(f).view(np.uint32)
+            assert sim.checksum(f) == int(a.sum(dtype=np.uint64))
+            r0, nr = rows // 3, rows // 2
+            assert sim.checksum(f, r0, nr) == int(a[r0:r0 + nr].sum(dtype=np.uint64))
+        with pytest.raises(pkg.FluidError):
+            sim.checksum(pkg.FIELD_PRESSURE, rows - 1, 2)
+        sim.close()
+    whole = pkg.FluidSim(512, lib=hip)
+    slab = pkg.FluidSim(512, lib=hip, slab_rank=1, slab_count=3)
+    v = np.random.default_rng(0).uniform(-1, 1, (512, 512, 2)).astype(np.float32)
+    whole.write(pkg.FIELD_VELOCITY, v)
+    slab.write(pkg.FIELD_VELOCITY, v[slab.row0:slab.row0 + slab.rows])
+    assert slab.checksum(pkg.FIELD_VELOCITY) == whole.checksum(pkg.FIELD_VELOCITY, slab.row0, slab.rows)

@@ -506,6 +506,13 @@ def test_bench_starts_its_own_ranks():
     # the library-driven exchange was verified against the whole-domain run and timed
     assert rec["exchange_mode"] == "staged" and rec["slab_matches_whole_domain"] is True and rec["attempt"] == 0
     assert rec["comm"]["attached"] and rec["halo_bytes_per_step_per_rank"] > 0
+    # what makes a first multi-GPU line auditable
+    assert rec["rccl_ranks"] is None                      # the rehearsal transport is not RCCL
+    assert len(rec["per_rank_ms_per_step"]) == 2 and all(v > 0 for v in rec["per_rank_ms_per_step"])
+    assert 0 < rec["compute_only_ms_per_step"] and len(rec["compute_only_per_rank_ms_per_step"]) == 2
+    assert abs(rec["exposed_comm_ms_per_step"] - (rec["ms_per_step"] - rec["compute_only_ms_per_step"])) < 1e-3
+    assert rec["roofline"]["bound"] == "hbm" and rec["roofline"]["frac"] > 0 and rec["roofline"]["kernel"] in rec["slab_kernels_rank0"]
+    assert rec["verified_after_steps"] == [3, 19]
 
 
 @pytest.mark.gpu
