@@ -43,6 +43,7 @@ class FluidParams(C.Structure):
         ("dt", C.c_float), ("viscosity", C.c_float), ("splat_radius", C.c_float),
         ("device", C.c_int), ("flags", C.c_uint), ("slab_rank", C.c_int), ("slab_count", C.c_int),
         ("halo_rows", C.c_int), ("pressure_groups", C.c_int), ("ny", C.c_int), ("inner_slabs", C.c_int), ("reserved", C.c_int * 2),
+        ("n_devices", C.c_int), ("device_ids", C.c_int * 8),
     ]
 
 
@@ -251,7 +252,7 @@ class FluidSim:
                  viscosity: Optional[float] = None, splat_radius: Optional[float] = None,
                  device: int = 0, flags: int = 0, slab_rank: int = 0, slab_count: int = 0,
                  halo_rows: int = 0, pressure_groups: int = 0, ny: int = 0, inner_slabs: int = 0,
-                 lib: Optional[FluidLib] = None):
+                 devices=None, lib: Optional[FluidLib] = None):
         self.lib = lib or _get_default_lib()
         p = self.lib.default_params()
         if n is not None:
@@ -271,6 +272,10 @@ class FluidSim:
         p.pressure_groups = pressure_groups
         p.ny = ny   # rows; 0 = n (square, the reference's case); n is then the number of columns
         p.inner_slabs = inner_slabs   # >= 2: the domain as that many slabs side by side on this GPU (fluid.h)
+        if devices:                   # one context over several GPUs: slab g on devices[g] (fluid.h, n_devices)
+            p.n_devices = len(devices)
+            for i, d in enumerate(devices):
+                p.device_ids[i] = d
         self.params = p
         self._h = C.c_void_p()
         rc = self.lib.dll.fluid_init(C.byref(self._h), C.byref(p))

@@ -123,6 +123,7 @@ struct fluid_ctx {
   hipEvent_t ev_fork = nullptr;     // this context's stream -> the slabs' streams
   std::vector<hipEvent_t> ev_done;  // ... and back
   bool inner_posted = false;        // the halo copies for the current state are enqueued
+  bool peer_copies = false;         // halo rows move by hipMemcpyAsync device to device (slabs on different GPUs)
   int inner_of = 0;                 // > 0: this context is one of that many inner slabs
   bool prof = false;
   int enq_rc = 0;          // first failure while enqueueing (a launch_* that refused, a failed memset); see check_launch
@@ -773,11 +774,20 @@ static int init_ctx(fluid_ctx **out, const fluid_params *p, int inner_of) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return FLUID_E_DEVICE;  // no CPU fallback
   if (prm.device < 0 || prm.device >= ndev) return FLUID_E_INVALID;
+  if (prm.n_devices < 0 || prm.n_devices > 8) return FLUID_E_INVALID;
+  if (prm.n_devices > 0 && !inner_of) {  // several GPUs under one context: slab g on device_ids[g]
+    if (prm.inner_slabs > 1 || prm.slab_count > 1) return FLUID_E_INVALID;
+    for (int g = 0; g < prm.n_devices; ++g)
+      if (prm.device_ids[g] < 0 || prm.device_ids[g] >= ndev) return FLUID_E_INVALID;
+    prm.device = prm.device_ids[0];
+    if (prm.n_devices == 1) prm.n_devices = 0;  // one slab: the plain context on that device
+    else return inner_init(out, prm);
+  }
   if (prm.inner_slabs >= 2 && !inner_of) return inner_init(out, prm);
   fluid_ctx *c = new (std::nothrow) fluid_ctx();
   if (!c) return FLUID_E_NOMEM;
   c->prm = prm;
-  c->inner_of = inner_of;
+  c->inner_of = inner_of < 0 ? 0 : inner_of;  // < 0: a slab of a several-GPU context: it has its GPU to itself
   c->g = Geom{prm.n, si.store_row0, si.store_rows, prm.ny ? prm.ny : prm.n};
   c->row0 = si.row0;
   c->rows = si.rows;
@@ -1706,7 +1716,8 @@ static int inner_fail(fluid_ctx *P, const fluid_ctx *s, int rc) {
 }
 
 static int inner_init(fluid_ctx **out, const fluid_params &prm) {
-  const int G = prm.inner_slabs;
+  const bool multi = prm.n_devices >= 2;  // the slabs on device_ids[] instead of side by side on prm.device
+  const int G = multi ? prm.n_devices : prm.inner_slabs;
   if (prm.slab_count > 1 || G > 16) return FLUID_E_UNSUPPORTED;  // no slabs of slabs
   if (prm.flags & (FLUID_FLAG_VORTICITY | FLUID_FLAG_UNFUSED)) return FLUID_E_UNSUPPORTED;
   fluid_ctx *P = new (std::nothrow) fluid_ctx();
@@ -1735,16 +1746,27 @@ static int inner_init(fluid_ctx **out, const fluid_params &prm) {
       }
     }
     HIPCHK(P, hipEventCreateWithFlags(&P->ev_fork, hipEventDisableTiming));
+    bool one_device = true;
     for (int r = 0; r < G; ++r) {
       fluid_params sp = prm;
       sp.inner_slabs = 0;
+      sp.n_devices = 0;
+      if (multi) sp.device = prm.device_ids[r];
+      one_device = one_device && sp.device == prm.device;
       sp.slab_rank = r;
       sp.slab_count = G;
       sp.pressure_groups = 0;
       fluid_ctx *s = nullptr;
-      const int src = init_ctx(&s, &sp, G);
+      // slabs that share a GPU size their launches to their share of it; alone on its GPU a slab is a rank
+      int share = G;
+      if (multi) {
+        share = 0;
+        for (int q = 0; q < G; ++q) share += prm.device_ids[q] == prm.device_ids[r];
+      }
+      const int src = init_ctx(&s, &sp, share > 1 ? share : -1);
       if (src) return src;  // e.g. FLUID_E_UNSUPPORTED: a slab too short for its halo
       P->subs.push_back(s);
+      HIPCHK(P, hipSetDevice(sp.device));  // the events a slab's stream records live on its device
       hipEvent_t e = nullptr;
       HIPCHK(P, hipEventCreateWithFlags(&e, hipEventDisableTiming));
       P->ev_done.push_back(e);
@@ -1753,6 +1775,22 @@ static int inner_init(fluid_ctx **out, const fluid_params &prm) {
       s->interior_split = env_int("FLUID_INTERIOR_SPLIT", 1);  // nothing slow has to get in between: one launch
       s->interior_split = s->interior_split < 1 ? 1 : s->interior_split > 8 ? 8 : s->interior_split;
     }
+    P->peer_copies = !one_device || env_int("FLUID_FORCE_PEER_COPY", 0) != 0;
+    if (!one_device) {
+      // no hipGraph across devices (not tried: nothing here has more than one GPU); peer access lets
+      // the copies go GPU to GPU over xGMI, without it the runtime stages them — either way correct
+      P->comm_graph = false;
+      snprintf(P->comm_note, sizeof P->comm_note, "slabs on several devices: direct launches");
+      for (int r = 0; r + 1 < G; ++r) {
+        const int a = P->subs[r]->prm.device, b = P->subs[r + 1]->prm.device;
+        if (a == b) continue;
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, a, b) == hipSuccess && can) { (void)hipSetDevice(a); (void)hipDeviceEnablePeerAccess(b, 0); }
+        if (hipDeviceCanAccessPeer(&can, b, a) == hipSuccess && can) { (void)hipSetDevice(b); (void)hipDeviceEnablePeerAccess(a, 0); }
+        (void)hipGetLastError();  // "already enabled" is fine
+      }
+    }
+    HIPCHK(P, hipSetDevice(prm.device));
     return FLUID_OK;
   }();
   if (rc != FLUID_OK) {
@@ -1763,19 +1801,28 @@ static int inner_init(fluid_ctx **out, const fluid_params &prm) {
   return FLUID_OK;
 }
 
+// Whatever is enqueued on a slab's stream is enqueued with that slab's device current (the slabs of a
+// several-GPU context live on different devices; a no-op when they share one).
+#define ON_DEVICE_OF(P, s) HIPCHK((P), hipSetDevice((s)->prm.device))
+
 // The slabs' streams pick up after this context's stream ...
 static int inner_fork(fluid_ctx *P) {
   HIPCHK(P, hipSetDevice(P->prm.device));
   HIPCHK(P, hipEventRecord(P->ev_fork, P->stream));
-  for (fluid_ctx *s : P->subs) HIPCHK(P, hipStreamWaitEvent(s->stream, P->ev_fork, 0));
+  for (fluid_ctx *s : P->subs) {
+    ON_DEVICE_OF(P, s);
+    HIPCHK(P, hipStreamWaitEvent(s->stream, P->ev_fork, 0));
+  }
   return FLUID_OK;
 }
 // ... and it picks up after them (pushes included: they are on the slabs' streams).
 static int inner_join(fluid_ctx *P) {
   for (size_t i = 0; i < P->subs.size(); ++i) {
+    ON_DEVICE_OF(P, P->subs[i]);
     HIPCHK(P, hipEventRecord(P->ev_done[i], P->subs[i]->stream));
-    HIPCHK(P, hipStreamWaitEvent(P->stream, P->ev_done[i], 0));
   }
+  HIPCHK(P, hipSetDevice(P->prm.device));
+  for (size_t i = 0; i < P->subs.size(); ++i) HIPCHK(P, hipStreamWaitEvent(P->stream, P->ev_done[i], 0));
   return FLUID_OK;
 }
 
@@ -1783,6 +1830,7 @@ static int inner_join(fluid_ctx *P) {
 // stream, once the neighbour no longer reads them (its ev_ready, recorded for the state in question).
 static int inner_push(fluid_ctx *P, size_t i) {
   fluid_ctx *s = P->subs[i];
+  ON_DEVICE_OF(P, s);
   for (int dir = -1; dir <= 1; dir += 2) {
     if (dir < 0 ? !s->has_lo : !s->has_hi) continue;
     fluid_ctx *q = P->subs[i + dir];
@@ -1793,7 +1841,10 @@ static int inner_push(fluid_ctx *P, size_t i) {
       const size_t row = (size_t)s->g.n * fs.esize, bytes = fq.rows * row;
       const size_t rs = dir < 0 ? s->own_r0 : s->own_r0 + s->rows - fq.rows;  // my owned rows next to that neighbour
       const size_t rd = dir < 0 ? q->own_r0 + q->rows : q->own_r0 - fq.rows;  // its halo rows on my side
-      launch_copy_block(s->stream, fq.base + rd * row, fs.base + rs * row, bytes);
+      // (the neighbour on another GPU: a device-to-device copy, peer to peer over xGMI where the two
+      // can reach each other; on the same GPU the copy kernel, which gets onto a busy device sooner)
+      if (P->peer_copies) HIPCHK(P, hipMemcpyAsync(fq.base + rd * row, fs.base + rs * row, bytes, hipMemcpyDeviceToDevice, s->stream));
+      else launch_copy_block(s->stream, fq.base + rd * row, fs.base + rs * row, bytes);
     }
   }
   HIPCHK(P, hipEventRecord(s->ev_halo, s->stream));
@@ -1803,7 +1854,10 @@ static int inner_push(fluid_ctx *P, size_t i) {
 // Halo rows for the current state, unless the pushes are already enqueued.
 static int inner_refresh(fluid_ctx *P) {
   if (P->inner_posted) return FLUID_OK;
-  for (fluid_ctx *s : P->subs) HIPCHK(P, hipEventRecord(s->ev_ready, s->stream));
+  for (fluid_ctx *s : P->subs) {
+    ON_DEVICE_OF(P, s);
+    HIPCHK(P, hipEventRecord(s->ev_ready, s->stream));
+  }
   for (size_t i = 0; i < P->subs.size(); ++i) {
     const int rc = inner_push(P, i);
     if (rc) return rc;
@@ -1815,6 +1869,7 @@ static int inner_refresh(fluid_ctx *P) {
 // A slab's stream waits for its neighbours' pushes into its halo rows.
 static int inner_wait_halos(fluid_ctx *P, size_t i) {
   fluid_ctx *s = P->subs[i];
+  ON_DEVICE_OF(P, s);
   if (s->has_lo) HIPCHK(P, hipStreamWaitEvent(s->stream, P->subs[i - 1]->ev_halo, 0));
   if (s->has_hi) HIPCHK(P, hipStreamWaitEvent(s->stream, P->subs[i + 1]->ev_halo, 0));
   return FLUID_OK;
@@ -1833,6 +1888,7 @@ static int inner_enqueue(fluid_ctx *P, int nsteps, bool halos_joined = false) {
     if ((rc = inner_refresh(P))) return rc;
     for (size_t i = 0; i < G; ++i) {
       fluid_ctx *s = P->subs[i];
+      ON_DEVICE_OF(P, s);
       if (!(halos_joined && k == 0) && (rc = inner_wait_halos(P, i))) return rc;
       // enq_velocity_head in two pieces, with the event between them
       const int m_diff = s->prm.pressure_iters + 1;
@@ -1844,7 +1900,7 @@ static int inner_enqueue(fluid_ctx *P, int nsteps, bool halos_joined = false) {
     }
     for (size_t i = 0; i < G; ++i) {
       fluid_ctx *s = P->subs[i];
-      if ((rc = inner_push(P, i))) return rc;
+      if ((rc = inner_push(P, i))) return rc;  // (leaves slab i's device current)
       enq_gradient_density_rows(s, false);
       s->pgroup = 0;
       s->tail_edges_done = false;

@@ -9,9 +9,11 @@
  *
  *   fluid_headless [--n N] [--ny ROWS] [--diffusion D] [--jacobi J] [--steps S] [--warmup W]
  *                  [--windows K] [--unfused] [--no-graph] [--vorticity] [--device I]
- *                  [--dump PREFIX] [--splats] [--inner-slabs G]
+ *                  [--dump PREFIX] [--splats] [--inner-slabs G] [--devices I,J,...]
  *       timed run on the seeded splat script; prints one JSON line (--inner-slabs: the domain as G
- *       slabs side by side on the one GPU, fluid_params.inner_slabs)
+ *       slabs side by side on the one GPU, fluid_params.inner_slabs; --devices: ONE process, the
+ *       domain as one row slab per listed GPU, fluid_params.n_devices / device_ids — the shape of
+ *       the reference's main(), kernel.cu:887-946, over several GPUs)
  *
  *   ... --replay FILE [--frames F] [--window W H]
  *       replays a recorded session instead (kernel.cu:858-878, :813-856): events of frame f are
@@ -371,6 +373,15 @@ int main(int argc, char **argv) {
     else if (!strcmp(argv[i], "--pressure-groups") && i + 1 < argc) prm.pressure_groups = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--comm-file") && i + 1 < argc) comm_file = argv[++i];
     else if (!strcmp(argv[i], "--inner-slabs") && i + 1 < argc) prm.inner_slabs = atoi(argv[++i]); /* fluid.h: G slabs side by side on this GPU */
+    else if (!strcmp(argv[i], "--devices") && i + 1 < argc) { /* fluid.h: several GPUs under one context */
+      const char *q = argv[++i];
+      prm.n_devices = 0;
+      while (*q && prm.n_devices < 8) {
+        prm.device_ids[prm.n_devices++] = (int)strtol(q, (char **)&q, 10);
+        if (*q == ',') ++q;
+      }
+      if (*q || prm.n_devices < 1) { fprintf(stderr, "--devices takes 1 to 8 comma-separated ordinals\n"); return 2; }
+    }
     else { fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
   }
   fluid_ctx *ctx = NULL;

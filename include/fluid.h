@@ -99,7 +99,28 @@ typedef struct fluid_params {
                           = run the domain as G row slabs of THIS GPU side by side, one HIP
                           stream each ("inner slabs", see below)                          */
   int reserved[2];     /* must be zero                                        */
+  int n_devices;       /* 0: one context on `device` (above).  G >= 1: ONE process drives G GPUs, as
+                          the reference's main() drives its one (kernel.cu:887-946): the domain is cut
+                          into G row slabs, slab g lives on device_ids[g], and this context answers for
+                          the whole grid ("several GPUs under one context", below).  Not together with
+                          inner_slabs or slab_count.                                              */
+  int device_ids[8];   /* HIP device ordinals, slab 0 (rows from 0) first; an ordinal may repeat */
 } fluid_params;
+
+/*
+ * Several GPUs under one context (fluid_params.n_devices = G, device_ids[]; SURVEY.md 8b's
+ * single-process contract; no counterpart in the reference, which is single-GPU).  The context is the
+ * parent of G slab contexts, one per entry of device_ids, each with its own stream on its own device;
+ * fluid_step enqueues every slab's launches from the calling thread and moves the halo rows between
+ * neighbouring slabs with device-to-device copies on the sending slab's stream (peer copies over xGMI
+ * when the two devices differ), ordered by events — the scheme of the inner slabs above, with the
+ * children placed on different devices.  fluid_read returns the whole grid, slabs gathered in y order;
+ * fluid_write / fluid_add_source / fluid_reset / fluid_diagnostics fan out.  Same limits as inner slabs.
+ * With every ordinal the same the G slabs share that GPU (that is what the builder's one-GPU boxes
+ * could run: bit-identical to the plain context, tests/test_inner_slabs.py); with G different GPUs
+ * nothing has been measured, and steps are enqueued directly (no hipGraph across devices).  One process
+ * per GPU with fluid_comm_* (RCCL) is the other multi-GPU form.
+ */
 
 /*
  * Inner slabs (fluid_params.inner_slabs = G >= 2; no counterpart in the reference).  The launches of a

@@ -239,3 +239,52 @@ def test_inner_slabs_as_one_hipgraph_under_the_system_runtime(pkg, hip):
     r = subprocess.run([sys.executable, "-c", GRAPH_SCRIPT % {"root": ROOT}], capture_output=True, text=True, timeout=110,
                        env=dict(os.environ))
     assert r.returncode == 0 and "inner graphs ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("G,peer", [(1, False), (2, False), (3, True), (4, False)])
+def test_several_gpus_under_one_context_with_every_ordinal_zero(pkg, hip, G, peer, monkeypatch):
+    """SURVEY.md 8b's single-process contract (fluid_params.n_devices / device_ids): one context, the
+    domain as one row slab per listed device, fluid_read gathering the slabs in y order.  A one-GPU
+    box can only list device 0 G times — the slabs then share it — which must give the bits of the
+    plain context, call for call, also with the halo rows moved by the device-to-device copies that
+    slabs on different GPUs use (FLUID_FORCE_PEER_COPY).  With G different GPUs: unmeasured."""
+    if peer:
+        monkeypatch.setenv("FLUID_FORCE_PEER_COPY", "1")
+    n, J = 768, 20
+    plain = pkg.FluidSim(n, lib=hip, pressure_iters=J)
+    multi = pkg.FluidSim(n, lib=hip, pressure_iters=J, devices=[0] * G)
+    assert (multi.n, multi.row0, multi.rows) == (n, 0, n)
+    a, b = drive(pkg, plain, SCRIPT), drive(pkg, multi, SCRIPT)
+    for i, (x, y) in enumerate(zip(a, b)):
+        if "velocity" in x:
+            for f in FIELDS:
+                assert_bit_equal(y[f], x[f], f"{f} at read {i} G={G}")
+    multi.sync()
+
+
+def test_several_gpus_refusals_and_the_c_host(pkg, hip):
+    import os
+    import subprocess
+    from util import ROOT
+    for bad in ([0, 7], [-1], [0] * 9):
+        if len(bad) > 8:
+            with pytest.raises((pkg.FluidError, IndexError)):
+                pkg.FluidSim(256, lib=hip, devices=bad)
+            continue
+        with pytest.raises(pkg.FluidError) as e:
+            pkg.FluidSim(256, lib=hip, devices=bad)     # the box has one GPU: ordinal 7 does not exist
+        assert e.value.code == E_INVALID
+    with pytest.raises(pkg.FluidError) as e:
+        pkg.FluidSim(256, lib=hip, devices=[0, 0], inner_slabs=2)
+    assert e.value.code == E_INVALID
+    exe = os.path.join(ROOT, "host", "fluid_headless")
+    outs = []
+    for extra in ([], ["--devices", "0,0,0"]):
+        r = subprocess.run([exe, "--n", "512", "--jacobi", "20", "--steps", "6", "--warmup", "0", "--windows", "1"] + extra,
+                           capture_output=True, text=True, timeout=100)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout.strip().splitlines()[-1])
+    import json
+    one, three = json.loads(outs[0]), json.loads(outs[1])
+    for k in ("max_abs_u", "max_abs_v", "max_abs_p", "max_abs_div", "max_jacobi_update"):
+        assert one[k] == three[k], (k, one[k], three[k])      # printed with 9 digits: the same floats
