@@ -12,7 +12,16 @@
 #include "fluid_internal.h"
 
 #include <dlfcn.h>
-#include <rccl/rccl.h>
+
+// The handful of RCCL declarations this file needs, stated here (they are RCCL's / NCCL's stable
+// public ABI: rccl.h, nccl.h) so that building the library needs no RCCL header either — the
+// library itself is only ever bound to librccl at run time.
+extern "C" {
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;  // NCCL_UNIQUE_ID_BYTES
+typedef enum { ncclSuccess = 0 } ncclResult_t;         // every other value is an error
+typedef enum { ncclChar = 0 } ncclDataType_t;          // ncclInt8 = ncclChar = 0
+}
 
 #include <cstdio>
 #include <cstring>
@@ -78,7 +87,7 @@ struct RcclUser {
 int note(RcclUser *u, ncclResult_t r, const char *what) {
   if (r == ncclSuccess) return 0;
   snprintf(u->err, sizeof u->err, "%s: %s", what, g_api.GetErrorString ? g_api.GetErrorString(r) : "RCCL error");
-  return (int)r ? (int)r : -1;
+  return (int)r;
 }
 
 int t_group_start(void *user) { return note((RcclUser *)user, g_api.GroupStart(), "ncclGroupStart"); }

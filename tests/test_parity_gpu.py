@@ -205,12 +205,13 @@ def test_full_size_4096_one_step_bit_exact(pkg, hip, oracle):
         assert_bit_equal(gpu.read(fid), ref.read(fid), f"4096^2 {f}")
 
 
-def test_large_grid_fused_equals_unfused(pkg, hip):
+@pytest.mark.parametrize("J", [40, 200])
+def test_large_grid_fused_equals_unfused(pkg, hip, J):
     """Size-independent property at a BASELINE multi-GPU size (8192^2, single GPU here): the
     temporally blocked path and the straight one-launch-per-reference-launch path agree bit for
     bit, so the full-size fused result inherits the small-size oracle parity of the straight
-    kernels."""
-    n, J = 8192, 40
+    kernels.  J = 200 is BASELINE.json configs[4] at full size (15 pressure launches of 13-14 sweeps)."""
+    n = 8192
     outs = []
     for flags in (0, pkg.FLAG_UNFUSED):
         s = pkg.FluidSim(n, lib=hip, pressure_iters=J, flags=flags)
