@@ -73,19 +73,19 @@ def cpu_threads():
         return max(1, min(16, os.cpu_count() or 1))
 
 
-def cpu_baseline(pkg, D, J, budget_s=12.0, threads=1):
-    """The host-C oracle (oracle/fluid_ref.c) on a bounded sample of the workload: a 1024^2 grid
-    with the workload's D and J, as many steps as fit the budget.  threads=1: the serial build (the
-    contract's `cpu_baseline`); threads>1: the same source built with -fopenmp (bit-identical,
-    tests/test_oracle_kat.py), reported separately as `cpu_baseline_parallel`."""
+def cpu_baseline(pkg, D, J, budget_s=12.0, threads=1, n=1024):
+    """The host-C oracle (oracle/fluid_ref.c) on a bounded sample of the workload: an n x n grid
+    (1024^2 unless told otherwise) with the workload's D and J, as many steps as fit the budget.
+    threads=1: the serial build (the contract's `cpu_baseline`); threads>1: the same source built
+    with -fopenmp (bit-identical, tests/test_oracle_kat.py), reported as `cpu_baseline_parallel`."""
     path = os.path.join(ROOT, "oracle", "liboracle_fluid.so" if threads == 1 else "liboracle_fluid_omp.so")
     if threads > 1:
         os.environ["OMP_NUM_THREADS"] = str(threads)  # read by libgomp when the library is loaded
     lib = pkg.FluidLib(path)
-    n = 1024
     sim = pkg.FluidSim(n, diffusion_iters=D, pressure_iters=J, lib=lib)
     seeded_warm_state(pkg, sim)
-    sim.step(1)  # warm caches / leave the all-zero state
+    if budget_s > 0:
+        sim.step(1)  # warm caches / leave the all-zero state (the one-step full-size sample runs cold)
     steps, t0 = 0, time.perf_counter()
     while True:
         sim.step(1)
@@ -93,12 +93,26 @@ def cpu_baseline(pkg, D, J, budget_s=12.0, threads=1):
         el = time.perf_counter() - t0
         if el >= budget_s or steps >= 400:
             break
+    sim.close()   # 16 GB of host memory at 16384^2
     return {
         "value": round(n * n * steps / el / 1e9, 6), "unit": "GCUPS", "cores": threads, "kind": "port",
         "sample": f"{n}x{n} grid, D={D}, J={J}, {steps} steps, seeded splats, "
                   + ("serial C oracle" if threads == 1 else f"C oracle with OpenMP row loops, {threads} threads")
                   + f" (gcc -O2 -ffp-contract=off), {el:.1f} s",
     }
+
+
+def kernel_sources_sha():
+    """sha256 over the kernel sources (csrc/fluid_kernels*.hip, fluid_internal.h) in name order: what
+    profiles/pmc_traffic.json's counters were collected on is compared with what runs now."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "fluid-simulation_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(csrc, "fluid_kernels*.hip")) + [os.path.join(csrc, "fluid_internal.h")]):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def load_pmc(workload):
@@ -152,7 +166,10 @@ def roofline_from_profile(sim, steps, workload, t_step):
         "frac_moved": round(moved_rate / HBM_PEAK_GBPS, 4),
         "traffic_GBps": round(moved, 1) if moved else None,
         "traffic_frac": round(moved / HBM_PEAK_GBPS, 4) if moved else None,
+        # the replayed counters belong to other kernel sources than the ones this run used
+        "traffic_stale": (pmc.get("_kernels_sha") != kernel_sources_sha()) if pmc else None,
         "traffic_collected": ({"commit": pmc.get("_commit"), "date": pmc.get("_date"), "workload": pmc.get("_workload"),
+                               "kernels_sha": pmc.get("_kernels_sha"),
                                "source": pmc.get("_source"), "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                                "bench.py on an MI355X; replayed, not measured in this run"} if pmc else None),
     }
@@ -318,7 +335,16 @@ def main():
                 s3.close()
         out["other_workloads"] = extra
     if not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(pkg, D, J)
+        # `cpu_baseline`: the serial port on the workload's own grid when ONE step of it fits the
+        # contract's 10-30 s of CPU work (16384^2, J = 40: about 20 s on one core, 16 GB of host memory),
+        # judged from a 3 s probe at 1024^2 (kept as cpu_baseline_probe); else the 1024^2 sample.
+        probe = cpu_baseline(pkg, D, J, budget_s=3.0)
+        est = n * n / (probe["value"] * 1e9)
+        if n > 1024 and est <= float(os.environ.get("FLUID_BENCH_CPU_STEP_LIMIT", "40")):
+            full = cpu_baseline(pkg, D, J, budget_s=0.0, n=n)   # budget 0: exactly one timed step
+            out["cpu_baseline"], out["cpu_baseline_probe"] = full, probe
+        else:
+            out["cpu_baseline"] = cpu_baseline(pkg, D, J)
         out["cpu_baseline_config0"] = cpu_baseline_config0(pkg)
         nthr = cpu_threads()
         if nthr > 1 and os.path.exists(os.path.join(ROOT, "oracle", "liboracle_fluid_omp.so")):

@@ -63,6 +63,10 @@ if len(sys.argv) > 3:  # also write the table bench.py reads for roofline.traffi
     except Exception:
         table["_commit"] = None
     table["_date"] = datetime.date.today().isoformat()
+    # what the counters were collected ON: bench.py compares this with the kernel sources it runs with
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import kernel_sources_sha
+    table["_kernels_sha"] = kernel_sources_sha()
     json.dump(table, open(sys.argv[3], "w"), indent=1, sort_keys=True)
 json.dump(out, open(dst + ".json", "w"), indent=1, sort_keys=True)
 with open(dst + ".txt", "w") as fh:
