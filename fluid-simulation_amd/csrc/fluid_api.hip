@@ -758,6 +758,30 @@ int fluid_slab_plan(const fluid_params *p, fluid_slab_info *out) {
 
 static int inner_init(fluid_ctx **out, const fluid_params &prm);
 
+// Launch plan of the register pipelines by owned cells, from sweeps on MI355X; results do not depend
+// on it (tests run seven plans), FLUID_TB_* / FLUID_TILE override it.  One row per size class, with
+// the measurement the row came from.  (Up to 2^20 cells the LDS tiles run instead: init_ctx.)
+struct PlanRow {
+  long long below;   // owned cells < below
+  int kj, kd;        // sweeps per pressure / diffusion launch (at most)
+  int waves, waves_d;  // target waves per launch (diffusion: 0 = the same)
+  float rounds;      // > 0: size launches to this many resident rounds of workgroups instead (tb_chunk)
+  const char *measured;
+};
+static const PlanRow kPlan[] = {
+    {1ll << 23, 8, 10, 2048, 0, 0.f,
+     "2048^2: half a resident round, longer chunks, fewer halo rows redone (tools/plan_sweep.py r1; 0.177 ms r2)"},
+    {1ll << 24, 8, 5, 2048, 2900, 0.f,
+     "3072^2 0.353 -> 0.339 ms, a slab of 8 of 8192^2 J=200 1.07 -> 1.01 with 2900 diffusion waves (tools/waves_d_sweep.py r2)"},
+    {1ll << 25, 10, 10, 3900, 2900, 1.f,
+     "4096^2, a slab of 4 of 8192^2: ONE resident round at the kernel's own occupancy, within 1 % of the wave targets (tools/waves_sweep2.py r2)"},
+    {(1ll << 26) + 1, 14, 10, 6100, 0, 1.f,
+     "6144^2 1.197 -> 1.085 ms, 8192^2 1.903 -> 1.826, 8192^2 J=200 4.83 -> 4.43 with one resident round (tools/waves_sweep2.py r2)"},
+    {(1ll << 27) + 1, 14, 10, 6100, 0, 0.f, "a slab of 2 of 16384^2: 6100 waves, two rounds (tools/slab_time.py r1)"},
+    {0x7fffffffffffffffll, 14, 10, 16384, 0, 0.f,
+     "12288^2, 16384^2: 16384 waves, shorter chunks even out the end of a launch (tools/plan_sweep.py r1)"},
+};
+
 // inner_of > 0: the context is one of that many inner slabs of a whole-domain context (inner_init)
 static int init_ctx(fluid_ctx **out, const fluid_params *p, int inner_of) {
   if (!out) return FLUID_E_INVALID;
@@ -800,18 +824,8 @@ static int init_ctx(fluid_ctx **out, const fluid_params *p, int inner_of) {
   c->jg = c->groups > 1 ? si.halo_prs - 1 : prm.pressure_iters;
   c->has_lo = si.has_lo;
   c->has_hi = si.has_hi;
-  // Launch plan by owned cells (sweeps per launch for the pressure / diffusion loops, target
-  // waves per launch), from sweeps on MI355X (tools/plan_sweep.py, tools/slab_time.py; DESIGN.md
-  // 5.1).  Results do not depend on it; FLUID_TILE / FLUID_TB_* override it.
-  //   <= 2^20 (up to 1024^2): launch/latency bound -> LDS tiles (fluid_kernels_tile.hip), 10 / 10
-  //           sweeps per launch; one resident round of 64 x 32 tiles ends at 1024^2 (1088^2: 0.131 ms
-  //           against 0.123 ms for the pipeline)
-  //   < 2^24  (2048^2, 3072^2, a slab of 8 of 8192^2): 8 sweeps per pressure launch, 10 / 5 per diffusion
-  //           launch, 2048 waves: half a resident round (more waves: shorter chunks, more halo rows redone)
-  //   < 2^25  (4096^2, a slab of 4 of 8192^2): 10 / 10 sweeps, ONE resident round of workgroups
-  //   <= 2^26 (6144^2, 8192^2, slabs of 8 and 4 of 16384^2): 14 / 10 sweeps, ONE resident round
-  //   <= 2^27 (a slab of 2 of 16384^2): 14 / 10 sweeps, 6100 waves (two rounds)
-  //   above   (12288^2, 16384^2): 14 / 10 sweeps, 16384 waves (shorter chunks even out the tail)
+  // Launch plan by owned cells: LDS tiles up to 2^20 (1024^2: launch/latency bound; one resident round of
+  // 64 x 32 tiles ends there, 1088^2: 0.131 ms against 0.123 for the pipeline), then kPlan's rows.
   const long long owned = (long long)prm.n * si.rows;
   c->tile = env_int("FLUID_TILE", owned <= (1ll << 20) ? 1 : 0) != 0;
   c->tb_minchunk = 1;
@@ -826,24 +840,19 @@ static int init_ctx(fluid_ctx **out, const fluid_params *p, int inner_of) {
   // round, and with the chunks that long the deep pipelines pay (tools/inner_slabs_probe.py).
   else if (inner_of > 0 && owned < (1ll << 22)) { c->tb_kj = 10; c->tb_kd = 10; c->tb_waves = 2048 / inner_of; }
   else if (inner_of > 0) { c->tb_kj = 14; c->tb_kd = 10; c->tb_waves = 4096 / inner_of; c->tb_waves_d = 3072 / inner_of; }
-  else if (owned < (1ll << 23)) { c->tb_kj = 8; c->tb_kd = 10; c->tb_waves = 2048; }
-  // From 2^24 to 2^26 owned cells (4096^2 ... 8192^2, slabs of 8 and 4 of 16384^2) a launch is sized to
-  // exactly ONE resident round of workgroups at its own kernel's occupancy (tb_chunk: 4 waves per SIMD
-  // for the 10-sweep pressure kernel, 3 for the 13/14-sweep ones and the diffusion), measured against the
-  // wave targets used before (tools/waves_sweep2.py): 6144^2 1.197 -> 1.085 ms, 8192^2 1.903 -> 1.826,
-  // 8192^2 J=200 4.83 -> 4.43, 4096^2 and the slabs of 16384^2 within 1 %.  Smaller grids do better
-  // under a round (2048 waves), larger ones with several (shorter chunks even out the end).
-  else if (owned < (1ll << 24)) {  // (waves_d 3900 before: 3072^2 0.353 -> 0.339 ms, slab of 8 of 8192^2 J=200 1.07 -> 1.01)
-    c->tb_kj = 8; c->tb_kd = 5; c->tb_waves = 2048; c->tb_waves_d = 2900;
+  else {
+    for (const PlanRow &r : kPlan) {
+      if (owned >= r.below) continue;
+      c->tb_kj = r.kj; c->tb_kd = r.kd; c->tb_waves = r.waves; c->tb_waves_d = r.waves_d; c->tb_rounds = r.rounds;
+      break;
+    }
     // wide and short (a slab of 8 of 8192^2: 76 strips, few chunk rows): 10 sweeps per pressure launch,
     // J = 200: 0.954 -> 0.886 ms per slab (J = 40: 0.344 -> 0.339); square grids of this size lose with
     // it (3072^2 J = 200: 0.914 -> 1.060)
-    if (prm.n >= 4 * si.rows) c->tb_kj = 10;
+    if (owned >= (1ll << 23) && owned < (1ll << 24) && prm.n >= 4 * si.rows) c->tb_kj = 10;
+    // (the fallback wave target when the runtime cannot tell the occupancy: slabs of 16384^2)
+    if (owned >= (1ll << 25) && owned <= (1ll << 26) && prm.n >= 12288) c->tb_waves = 3072;
   }
-  else if (owned < (1ll << 25)) { c->tb_kj = 10; c->tb_kd = 10; c->tb_waves = 3900; c->tb_waves_d = 2900; c->tb_rounds = 1.f; }
-  else if (owned <= (1ll << 26)) { c->tb_kj = 14; c->tb_kd = 10; c->tb_waves = prm.n >= 12288 ? 3072 : 6100; c->tb_rounds = 1.f; }
-  else if (owned <= (1ll << 27)) { c->tb_kj = 14; c->tb_kd = 10; c->tb_waves = 6100; }
-  else { c->tb_kj = 14; c->tb_kd = 10; c->tb_waves = 16384; }
   // non-temporal stores in the two streaming kernels (fluid_kernels.hip): measured break-even at
   // about 3072^2 stored cells (2048^2: 0.204 -> 0.215 ms with them, 4096^2: 0.586 -> 0.570 ms)
   // (inner slabs: by the whole domain's size, what the GPU's caches see — 4096^2 as two slabs: 0.525 -> 0.515 ms)
