@@ -835,7 +835,10 @@ static int init_ctx(fluid_ctx **out, const fluid_params *p, int inner_of) {
   c->tile_ty = env_int("FLUID_TILE_TY", owned <= 3 * (1ll << 17) ? 16 : 32);
   if (!tile_has_ty(c->tile_ty)) c->tile_ty = 32;
   c->tile_div = env_int("FLUID_TILE_DIV", 1) != 0;
-  if (c->tile) { c->tb_kj = 10; c->tb_kd = 10; }
+  // (pressure: 14 + 13 + 13 sweeps for J = 40 instead of 4 x 10 — a launch fewer; the taller tiles cost
+  // 16.4 us per launch instead of 13.4: 1024^2 81.6 -> 79.2 us per step, 768^2 74.9 -> 73.5, 512^2 J = 40
+  // 45.4 -> 43.7.  Two launches of 20 on 104 x 72 tiles lose from 768^2 up: 30.2 us each, 1024^2 92.3.)
+  if (c->tile) { c->tb_kj = 14; c->tb_kd = 10; }
   // Inner slabs share the GPU with their siblings: each launch is sized to its share of a resident
   // round, and with the chunks that long the deep pipelines pay (tools/inner_slabs_probe.py).
   else if (inner_of > 0 && owned < (1ll << 22)) { c->tb_kj = 10; c->tb_kd = 10; c->tb_waves = 2048 / inner_of; }

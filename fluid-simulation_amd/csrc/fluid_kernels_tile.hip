@@ -435,9 +435,10 @@ inline dim3 tile_grid(Geom g, int r0, int r1, int ty) { return dim3((g.n + TX - 
 
 // Sweep counts instantiated: the LDS tile grows with K (two planes of (TX + 2 HX) x (TY + 2K)
 // floats for the pressure, four for the velocity).  Tile heights: 32 and 16 rows.
-bool tile_has_k(int k, bool) {
+bool tile_has_k(int k, bool float2_field) {
   switch (k) {
     case 1: case 2: case 4: case 5: case 8: case 10: return true;
+    case 13: case 14: case 20: return !float2_field;  // pressure only: two planes of a 104 x 72 tile are 60 KB
     default: return false;
   }
 }
@@ -467,6 +468,9 @@ bool jacobi_tile_k(hipStream_t s, Geom g, int r0, int r1, int k, int ty, const f
     case 5: return jacobi_tile_ty<5, DIV>(s, g, r0, r1, ty, pin, vel, div_in, div_out, pout);
     case 8: return jacobi_tile_ty<8, DIV>(s, g, r0, r1, ty, pin, vel, div_in, div_out, pout);
     case 10: return jacobi_tile_ty<10, DIV>(s, g, r0, r1, ty, pin, vel, div_in, div_out, pout);
+    case 13: return jacobi_tile_ty<13, DIV>(s, g, r0, r1, ty, pin, vel, div_in, div_out, pout);
+    case 14: return jacobi_tile_ty<14, DIV>(s, g, r0, r1, ty, pin, vel, div_in, div_out, pout);
+    case 20: return jacobi_tile_ty<20, DIV>(s, g, r0, r1, ty, pin, vel, div_in, div_out, pout);
     default: return false;
   }
 }

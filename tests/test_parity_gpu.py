@@ -438,7 +438,7 @@ def test_pipeline_fill_with_chunks_shorter_and_longer_than_the_fill(pkg, hip, or
 
 
 @pytest.mark.parametrize("ty", [32, 16])
-@pytest.mark.parametrize("k", [1, 2, 4, 5, 8, 10])
+@pytest.mark.parametrize("k", [1, 2, 4, 5, 8, 10, 13, 14, 20])   # 13, 14, 20: pressure tiles only
 def test_lds_tiles_bit_exact(pkg, hip, oracle, k, ty, monkeypatch):
     """The small-grid path (fluid_kernels_tile.hip: K sweeps on a 64 x 32 or 64 x 16 tile held in LDS)
     gives the bits of the sweep-by-sweep oracle: grids that are not multiples of the tile, tiles cut
