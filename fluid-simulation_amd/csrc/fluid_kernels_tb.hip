@@ -481,6 +481,9 @@ template <class Op, int K, bool XEDGE> struct Pipe {
   // domain border the boundary rule never reads outward), and rows that must not be stored go
   // to a dump row instead of being skipped.
   __device__ __forceinline__ size_t off(int t) const {
+#ifdef TB_FAKE_NOHALO  // timing experiment only (wrong results): the y-halo rows of a chunk cost no new traffic
+    t = min(max(t, ya), yb - 1);
+#endif
     const int r = min(max(t - g.ybase, 0), g.L - 1);
     return (size_t)r * g.n + xc;
   }
