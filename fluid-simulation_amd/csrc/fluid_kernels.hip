@@ -137,6 +137,11 @@ __device__ __forceinline__ float2 linear_at_int(const float2 *t, Geom g, int m, 
 #ifndef ADV_RD
 #define ADV_RD 1
 #endif
+// (Round 3: a thread walking down four groups of ADV_ROWS rows with the NEXT group's velocities loaded
+// before it gathers for the current one — the first round trip of a backtrace overlapped with the second —
+// is slower everywhere: 16384^2 872 -> 1014 us, 8192^2 246 -> 272, 4096^2 80 -> 88
+// (profiles/r03/r3_adv_groups.log; bit-identical).  Four times fewer, four times longer workgroups lose
+// more than the overlap gives.)
 constexpr int ADV_ROWS_VEL = ADV_RV;   // measured: 1.33 -> 1.23 ms at 16384^2
 constexpr int ADV_ROWS_DENS = ADV_RD;  // float4 texels: more rows cost occupancy (1.82 -> 2.08 ms with 4)
 
