@@ -1982,13 +1982,16 @@ static int inner_steps(fluid_ctx *P, int nsteps, bool launch) {
       hipError_t ei = hipSuccess;
       if (!rc && e == hipSuccess) ei = hipGraphInstantiate(&ge.exec, ge.graph, nullptr, nullptr, 0);
       TR("instantiated");
+#undef TR
       if (rc || e != hipSuccess || ei != hipSuccess) {  // nothing of it has run: direct launches from now on
         snprintf(P->comm_note, sizeof P->comm_note, "inner slabs: graph capture given up (%s)",
                  rc ? "enqueue" : e != hipSuccess ? hipGetErrorString(e) : hipGetErrorString(ei));
         if (ge.graph) (void)hipGraphDestroy(ge.graph);
         (void)hipGetLastError();
         P->comm_graph = false;
-        return launch ? inner_direct(P, nsteps - s) : FLUID_OK;
+        if (launch) return inner_direct(P, nsteps - s);
+        for (size_t i = 0; i < G; ++i) set_state(P->subs[i], first[i]);  // only building: nothing has run
+        return FLUID_OK;
       }
       it = P->graphs.emplace(key, ge).first;
     }
