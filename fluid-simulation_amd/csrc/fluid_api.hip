@@ -771,10 +771,13 @@ struct PlanRow {
 static const PlanRow kPlan[] = {
     {1ll << 23, 8, 10, 2048, 0, 0.f,
      "2048^2: half a resident round, longer chunks, fewer halo rows redone (tools/plan_sweep.py r1; 0.177 ms r2)"},
-    {1ll << 24, 8, 5, 2048, 2900, 0.f,
-     "3072^2 0.353 -> 0.339 ms, a slab of 8 of 8192^2 J=200 1.07 -> 1.01 with 2900 diffusion waves (tools/waves_d_sweep.py r2)"},
-    {1ll << 25, 10, 10, 3900, 2900, 1.f,
-     "4096^2, a slab of 4 of 8192^2: ONE resident round at the kernel's own occupancy, within 1 % of the wave targets (tools/waves_sweep2.py r2)"},
+    {1ll << 24, 14, 5, 2048, 2900, 1.f,
+     "r3 (profiles/r03/r3_plan_*.log): 14 sweeps per pressure launch and ONE resident round instead of 8 sweeps and "
+     "2048 / 2900 waves: 3584^2 0.435 -> 0.415 ms, a slab of 8 of 8192^2 0.343 -> 0.331 (J=200 0.914 -> 0.893), a slab of "
+     "2 of 4096^2 0.351 -> 0.337; 3072^2 unchanged at J=40 (0.347), 0.885 -> 0.898 at J=200"},
+    {1ll << 25, 14, 10, 3900, 2900, 1.f,
+     "4096^2, a slab of 4 of 8192^2: ONE resident round (tools/waves_sweep2.py r2); r3: 14 sweeps per pressure launch "
+     "instead of 10 (a launch fewer): 4096^2 0.531 -> 0.517 ms, J=200 1.330 -> 1.291, the slab 0.547 -> 0.529 (J=200 1.435 -> 1.351)"},
     {(1ll << 26) + 1, 14, 10, 6100, 0, 1.f,
      "6144^2 1.197 -> 1.085 ms, 8192^2 1.903 -> 1.826, 8192^2 J=200 4.83 -> 4.43 with one resident round (tools/waves_sweep2.py r2)"},
     {(1ll << 27) + 1, 14, 10, 6100, 0, 0.f, "a slab of 2 of 16384^2: 6100 waves, two rounds (tools/slab_time.py r1)"},
@@ -849,10 +852,6 @@ static int init_ctx(fluid_ctx **out, const fluid_params *p, int inner_of) {
       c->tb_kj = r.kj; c->tb_kd = r.kd; c->tb_waves = r.waves; c->tb_waves_d = r.waves_d; c->tb_rounds = r.rounds;
       break;
     }
-    // wide and short (a slab of 8 of 8192^2: 76 strips, few chunk rows): 10 sweeps per pressure launch,
-    // J = 200: 0.954 -> 0.886 ms per slab (J = 40: 0.344 -> 0.339); square grids of this size lose with
-    // it (3072^2 J = 200: 0.914 -> 1.060)
-    if (owned >= (1ll << 23) && owned < (1ll << 24) && prm.n >= 4 * si.rows) c->tb_kj = 10;
     // (the fallback wave target when the runtime cannot tell the occupancy: slabs of 16384^2)
     if (owned >= (1ll << 25) && owned <= (1ll << 26) && prm.n >= 12288) c->tb_waves = 3072;
   }
