@@ -769,12 +769,16 @@ struct PlanRow {
   const char *measured;
 };
 static const PlanRow kPlan[] = {
-    {1ll << 23, 8, 10, 2048, 0, 0.f,
-     "2048^2: half a resident round, longer chunks, fewer halo rows redone (tools/plan_sweep.py r1; 0.177 ms r2)"},
-    {1ll << 24, 14, 5, 2048, 2900, 1.f,
-     "r3 (profiles/r03/r3_plan_*.log): 14 sweeps per pressure launch and ONE resident round instead of 8 sweeps and "
-     "2048 / 2900 waves: 3584^2 0.435 -> 0.415 ms, a slab of 8 of 8192^2 0.343 -> 0.331 (J=200 0.914 -> 0.893), a slab of "
-     "2 of 4096^2 0.351 -> 0.337; 3072^2 unchanged at J=40 (0.347), 0.885 -> 0.898 at J=200"},
+    {9ll << 19, 8, 10, 2048, 0, 0.f,
+     "up to 2048^2: 8 sweeps per pressure launch, half a resident round: longer chunks, fewer halo rows redone "
+     "(tools/plan_sweep.py r1; 0.177 ms r2; r3 re-swept: within 1 % of the best of 48 plans from 1280^2 to 2048^2)"},
+    {1ll << 23, 10, 10, 2048, 0, 0.5f,
+     "r3 (profiles/r03/r3_sweep*.log): 10 sweeps and HALF a resident round of workgroups (counted per kernel, tb_chunk) "
+     "instead of 8 sweeps and 2048 waves: 2304^2 0.245 -> 0.217 ms, 2560^2 0.250 -> 0.240, 2816^2 0.318 -> 0.293"},
+    {1ll << 24, 14, 10, 2048, 2900, 1.f,
+     "r3 (profiles/r03/r3_plan_*.log, r3_sweep2.log): 14 sweeps per pressure launch, 10 per diffusion launch and ONE "
+     "resident round instead of 8 / 5 sweeps and 2048 / 2900 waves: 3072^2 0.347 -> 0.334 ms (J=200 0.900 -> 0.887), 3584^2 "
+     "0.435 -> 0.400, a slab of 8 of 8192^2 0.343 -> 0.317 (J=200 0.914 -> 0.881), a slab of 2 of 4096^2 0.351 -> 0.322"},
     {1ll << 25, 14, 10, 3900, 2900, 1.f,
      "4096^2, a slab of 4 of 8192^2: ONE resident round (tools/waves_sweep2.py r2); r3: 14 sweeps per pressure launch "
      "instead of 10 (a launch fewer): 4096^2 0.531 -> 0.517 ms, J=200 1.330 -> 1.291, the slab 0.547 -> 0.529 (J=200 1.435 -> 1.351)"},
@@ -852,6 +856,9 @@ static int init_ctx(fluid_ctx **out, const fluid_params *p, int inner_of) {
       c->tb_kj = r.kj; c->tb_kd = r.kd; c->tb_waves = r.waves; c->tb_waves_d = r.waves_d; c->tb_rounds = r.rounds;
       break;
     }
+    // the reference's own J = 10 (and anything up to it) in ONE pressure launch on the smallest pipeline
+    // grids too, where J = 40 prefers five launches of 8: 2048^2 J=10 0.127 -> 0.116 ms, 1536^2 0.0847 -> 0.0808
+    if (owned < (9ll << 19) && prm.pressure_iters <= 10) c->tb_kj = 10;
     // (the fallback wave target when the runtime cannot tell the occupancy: slabs of 16384^2)
     if (owned >= (1ll << 25) && owned <= (1ll << 26) && prm.n >= 12288) c->tb_waves = 3072;
   }
