@@ -862,10 +862,12 @@ static int init_ctx(fluid_ctx **out, const fluid_params *p, int inner_of) {
     // (the fallback wave target when the runtime cannot tell the occupancy: slabs of 16384^2)
     if (owned >= (1ll << 25) && owned <= (1ll << 26) && prm.n >= 12288) c->tb_waves = 3072;
   }
-  // non-temporal stores in the two streaming kernels (fluid_kernels.hip): measured break-even at
-  // about 3072^2 stored cells (2048^2: 0.204 -> 0.215 ms with them, 4096^2: 0.586 -> 0.570 ms)
+  // non-temporal stores in the two streaming kernels (fluid_kernels.hip).  Break-even re-measured in round 3
+  // (profiles/r03/r3_nt*.log) between 2048^2 (0.1765 -> 0.1829 ms with them) and 2304^2 (0.2154 -> 0.2100):
+  // on from 4.7 M stored cells (round 2: from 2^24; 2560^2 0.240 -> 0.233, 3072^2 0.332 -> 0.326, 3584^2
+  // 0.400 -> 0.393; slabs of that size 0-3 % faster).
   // (inner slabs: by the whole domain's size, what the GPU's caches see — 4096^2 as two slabs: 0.525 -> 0.515 ms)
-  c->nt_stores = env_int("FLUID_NT", (long long)prm.n * si.store_rows * (inner_of > 0 ? inner_of : 1) >= (1ll << 24) ? 1 : 0) != 0;
+  c->nt_stores = env_int("FLUID_NT", (long long)prm.n * si.store_rows * (inner_of > 0 ? inner_of : 1) >= (9ll << 19) ? 1 : 0) != 0;
   c->graph_steps = env_int("FLUID_GRAPH_STEPS", 16);
   if (c->graph_steps < 1) c->graph_steps = 1;
   c->direct_parts = env_int("FLUID_DIRECT_PARTS", 1) != 0;
