@@ -21,7 +21,7 @@ _FIELD_COMPONENTS = {FIELD_VELOCITY: 2, FIELD_DENSITY: 4, FIELD_PRESSURE: 1, FIE
 # Every symbol include/fluid.h declares (checked against the header text in tests).
 ABI_SYMBOLS = [
     "fluid_default_params", "fluid_init", "fluid_destroy", "fluid_reset", "fluid_add_source",
-    "fluid_step", "fluid_prepare_steps", "fluid_step_noalloc", "fluid_debug_sink", "fluid_advect_velocity", "fluid_diffuse", "fluid_vorticity", "fluid_project",
+    "fluid_step", "fluid_prepare_steps", "fluid_step_noalloc", "fluid_debug_sink", "fluid_debug_chain_trace", "fluid_advect_velocity", "fluid_diffuse", "fluid_vorticity", "fluid_project",
     "fluid_advect_density", "fluid_read", "fluid_write", "fluid_sync", "fluid_diagnostics", "fluid_checksum", "fluid_geometry",
     "fluid_strerror", "fluid_last_error", "fluid_time_steps", "fluid_profile_steps",
     "fluid_stream", "fluid_set_stream",
@@ -155,6 +155,7 @@ class FluidLib:
         sig("fluid_write", C.c_int, P, C.c_int, P, C.c_size_t)
         sig("fluid_diagnostics", C.c_int, P, C.POINTER(FluidDiag), required=False)
         sig("fluid_checksum", C.c_int, P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_ulonglong), required=False)
+        sig("fluid_debug_chain_trace", C.c_int, P, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), required=False)
         sig("fluid_geometry", C.c_int, P, C.POINTER(C.c_int), C.POINTER(C.c_int),
             C.POINTER(C.c_int))
         sig("fluid_strerror", C.c_char_p, C.c_int)
@@ -369,6 +370,15 @@ class FluidSim:
         d = FluidDiag()
         self._chk(self.lib.dll.fluid_diagnostics(self._h, C.byref(d)), "fluid_diagnostics")
         return d.as_dict()
+
+    def chain_trace(self, max_records=1 << 20):
+        """fluid_debug_chain_trace: (records, 4) uint64 time stamps of the last temporally blocked launch
+        (contexts made with FLUID_TB_TRACE=1)."""
+        buf = np.zeros(4 * max_records, np.uint64)
+        words = C.c_size_t(0)
+        self._chk(self.lib.dll.fluid_debug_chain_trace(self._h, buf.ctypes.data, buf.size, C.byref(words)),
+                  "fluid_debug_chain_trace")
+        return buf[:words.value - words.value % 4].reshape(-1, 4)
 
     def checksum(self, field: int, row0: int = 0, rows: int = 0) -> int:
         """fluid_checksum: sum of the 32-bit words of global rows [row0, row0 + rows) of the current

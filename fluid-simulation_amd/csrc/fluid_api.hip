@@ -94,6 +94,14 @@ struct fluid_ctx {
   int tb_kj = 10, tb_kd = 5, tb_cj = 2, tb_cd = 2, tb_waves = 8192, tb_minchunk = 4;
   float tb_rounds = 0.f;  // > 0: size the temporally blocked launches to this many resident rounds of workgroups (tb_chunk)
   int tb_waves_d = 0;  // target waves of the diffusion launches (0 = tb_waves): they hold more registers, so fewer are resident
+  // chained chunks (fluid_kernels_tb.hip, Pipe::run): vertically adjacent chunks hand each other their
+  // boundary rows through this buffer instead of both computing K rows of halo
+  bool tb_chain = false;
+  int tb_chain_kinds = 1;  // bit per kind of launch that is chained: 1 pressure (the only kind that gains), 2 divergence + pressure, 4 diffusion
+  TbChain chain{};
+  TbChain trace_only{};  // FLUID_TB_TRACE without chaining: only the trace pointer
+  void *chain_mem = nullptr;
+  size_t chain_words = 0, chain_flags = 0;  // capacity: 8-byte words of side records, flags
   bool tile_div = true;    // tile path: the last diffusion launch also writes the divergence (FLUID_TILE_DIV)
   bool div_ready = false;  // ... and did, for the projection about to be enqueued
   int tile_ty = 32;   // rows an LDS tile stores (16 on the smallest grids, see fluid_init)
@@ -320,7 +328,7 @@ void fill_pass_tables(fluid_ctx *c) {
 // a launch a few workgroups over a round pays a whole extra round for them (8192^2, J = 200:
 // 3034 waves asked for = 37 x 21 workgroups = 777 > 768 resident: 5.26 ms against 4.45 ms at 35 x 21).
 // Otherwise about tb_waves waves (the largest grids: many rounds, shorter chunks even out the end).
-int tb_chunk(const fluid_ctx *c, int kind, int k, int cols, int rows) {
+int tb_chunk_count(const fluid_ctx *c, int kind, int k, int cols) {
   int chunks = 0;
   const int resident = c->tb_rounds > 0.f ? tb_resident_blocks(kind, k, cols) : 0;
   if (resident > 0) {
@@ -332,10 +340,56 @@ int tb_chunk(const fluid_ctx *c, int kind, int k, int cols, int rows) {
     const int strips = (c->g.n + vw - 1) / vw;
     chunks = waves / strips;
   }
-  if (chunks < 1) chunks = 1;
+  return chunks < 1 ? 1 : chunks;
+}
+int tb_chunk(const fluid_ctx *c, int kind, int k, int cols, int rows) {
+  const int chunks = tb_chunk_count(c, kind, k, cols);
   int chunk = (rows + chunks - 1) / chunks;
   if (chunk < c->tb_minchunk * k) chunk = c->tb_minchunk * k;  // bound the y-halo recompute (2k rows per chunk)
+  if (c->tb_chain && ((c->tb_chain_kinds >> kind) & 1) && tb_has_k(k, cols, kind == 2) && cols == 2) {
+    // chained chunks: a multiple of the pipeline's slot period, long enough for fill and tail; a
+    // launch whose rows then fit one chunk (or whose k has no unrolled fill) runs unchained
+    // The bottom chunk has nobody to take rows from and ends the old way, k full steps later than
+    // the others; a launch that is one resident round ends with its slowest wave, so the bottom
+    // chunk is made k rows shorter: (chunks - 1) * chunk + (chunk - k) = rows.
+    const int m = tb_chain_chunk_multiple();
+    if (chunks > 1) chunk = (rows + k + chunks - 1) / chunks;
+    chunk = (chunk + m - 1) / m * m;
+    if (chunk < tb_chain_min_chunk(k)) chunk = tb_chain_min_chunk(k);
+  }
   return chunk;
+}
+// What goes along with a temporally blocked launch besides its arguments: the context's side buffer
+// if the launch is to run chained and fits it, and the trace buffer (FLUID_TB_TRACE).
+TbChain tb_extra(const fluid_ctx *c, int kind, int k, int cols, int chunk, int rows) {
+  TbChain x{};
+  const int chunks = (rows + chunk - 1) / chunk;
+  const bool fits = tb_chain_flags(c->g.n, k, cols, chunks) <= c->chain_flags;
+  if (c->trace_only.trace && fits) x.trace = c->trace_only.trace;
+  if (c->tb_chain && ((c->tb_chain_kinds >> kind) & 1) && c->chain_mem && fits && tb_chain_chunk_ok(k, cols, chunk, rows) &&
+      tb_chain_words(c->g.n, k, cols, kind == 2, chunks) <= c->chain_words) {
+    x.side = c->chain.side;
+    x.flags = c->chain.flags;
+    x.status = c->chain.status;
+  }
+  return x;
+}
+// What the plan's launches can need at most (a launch has at most tb_chunk_count chunk-rows, and
+// never more than its rows over the shortest chained chunk).
+void tb_chain_capacity(const fluid_ctx *c, size_t *words, size_t *flags) {
+  *words = *flags = 0;
+  auto one = [&](int kind, int k, int cols) {
+    if (k < 1 || cols != 2 || !tb_has_k(k, cols, kind == 2)) return;
+    int chunks = tb_chunk_count(c, kind, k, cols);
+    const int most = c->g.L / tb_chain_min_chunk(k) + 1;
+    if (chunks > most) chunks = most;
+    const size_t w = tb_chain_words(c->g.n, k, cols, kind == 2, chunks), f = tb_chain_flags(c->g.n, k, cols, chunks);
+    if (w > *words) *words = w;
+    if (f > *flags) *flags = f;
+  };
+  // (every kind, whichever of them FLUID_TB_CHAIN_KINDS chains: the trace buffer is sized by the flags)
+  for (int k : c->pass_d) one(2, k, c->tb_cd);
+  for (int k : c->pass_j) { one(0, k, c->tb_cj); one(1, k, c->tb_cj); }
 }
 
 bool use_tb(const fluid_ctx *c, int cols) {
@@ -368,9 +422,10 @@ void enq_diffuse(fluid_ctx *c, int out_m, bool with_div = false) {
       const int k = next_pass(c, left, true);
       ProfScope p(c, K_DIFFUSE_TB, 16.0 * k * cells, 16.0 * cells);
       const Range r = widened(c, out_m + left - k);
-      LAUNCH(c, launch_diffuse_tb(c->stream, c->g, r.r0, r.r1, k, c->tb_cd,
-                               tb_chunk(c, 2, k, c->tb_cd, r.r1 - r.r0), c->alpha, c->beta, c->vel[c->vin],
-                               c->vel[c->vin ^ 1], c->dump));
+      const int chunk = tb_chunk(c, 2, k, c->tb_cd, r.r1 - r.r0);
+      const TbChain extra = tb_extra(c, 2, k, c->tb_cd, chunk, r.r1 - r.r0);
+      LAUNCH(c, launch_diffuse_tb(c->stream, c->g, r.r0, r.r1, k, c->tb_cd, chunk, c->alpha, c->beta, c->vel[c->vin],
+                               c->vel[c->vin ^ 1], c->dump, &extra));
       c->vin ^= 1;
       left -= k;
     }
@@ -455,8 +510,10 @@ void enq_pressure_group(fluid_ctx *c, int g) {
       const int k = next_pass(c, left, false);
       ProfScope p(c, K_JACOBI_DIV_TB, 12.0 * cells + 12.0 * k * cells, 16.0 * cells);  // velocity in, divergence and p out
       const Range r = widened(c, div_m >= 0 ? div_m : 1 + left - k);
-      LAUNCH(c, launch_jacobi_div_tb(c->stream, c->g, r.r0, r.r1, k, c->tb_cj, tb_chunk(c, 1, k, c->tb_cj, r.r1 - r.r0),
-                                  c->vel[c->vin], c->div, c->prs[c->pin ^ 1], c->dump));
+      const int chunk = tb_chunk(c, 1, k, c->tb_cj, r.r1 - r.r0);
+      const TbChain extra = tb_extra(c, 1, k, c->tb_cj, chunk, r.r1 - r.r0);
+      LAUNCH(c, launch_jacobi_div_tb(c->stream, c->g, r.r0, r.r1, k, c->tb_cj, chunk, c->vel[c->vin], c->div,
+                                  c->prs[c->pin ^ 1], c->dump, &extra));
       c->pin ^= 1;
       left -= k;
     } else {
@@ -475,8 +532,10 @@ void enq_pressure_group(fluid_ctx *c, int g) {
       const int k = next_pass(c, left, false);
       ProfScope p(c, K_JACOBI_TB, 12.0 * k * cells, 12.0 * cells);
       const Range r = widened(c, 1 + left - k);
-      LAUNCH(c, launch_jacobi_tb(c->stream, c->g, r.r0, r.r1, k, c->tb_cj, tb_chunk(c, 0, k, c->tb_cj, r.r1 - r.r0),
-                              c->prs[c->pin], c->div, c->prs[c->pin ^ 1], c->dump));
+      const int chunk = tb_chunk(c, 0, k, c->tb_cj, r.r1 - r.r0);
+      const TbChain extra = tb_extra(c, 0, k, c->tb_cj, chunk, r.r1 - r.r0);
+      LAUNCH(c, launch_jacobi_tb(c->stream, c->g, r.r0, r.r1, k, c->tb_cj, chunk, c->prs[c->pin], c->div,
+                              c->prs[c->pin ^ 1], c->dump, &extra));
       c->pin ^= 1;
       left -= k;
     }
@@ -671,6 +730,11 @@ int ensure_vort(fluid_ctx *c) {
 
 // After the stream has drained: did an advection gather leave the rows it may read?
 int check_halo_flag(fluid_ctx *c) {
+  if (c->chain_mem) {  // chained chunks: did a wave give up waiting for its neighbour's rows?  (never seen)
+    int st = 0;
+    HIPCHK(c, hipMemcpy(&st, c->chain.status, sizeof st, hipMemcpyDeviceToHost));
+    if (st) return fail(c, FLUID_E_DEVICE, "a chained chunk gave up waiting for the rows of the chunk below it");
+  }
   if (!c->slab) return FLUID_OK;
   int flag = 0;
   HIPCHK(c, hipMemcpy(&flag, c->halo_flag, sizeof flag, hipMemcpyDeviceToHost));
@@ -884,6 +948,8 @@ static int init_ctx(fluid_ctx **out, const fluid_params *p, int inner_of) {
   if (env_int("FLUID_TB_WAVES", 0) > 0) c->tb_rounds = 0.f;  // an explicit wave target wins over the table's rounds
   c->tb_rounds = env_int("FLUID_TB_ROUNDS_PCT", (int)(c->tb_rounds * 100.f + 0.5f)) / 100.f;
   c->tb_minchunk = env_int("FLUID_TB_MINCHUNK", c->tb_minchunk);
+  c->tb_chain = env_int("FLUID_TB_CHAIN", c->tb_chain ? 1 : 0) != 0 && !c->tile;
+  c->tb_chain_kinds = env_int("FLUID_TB_CHAIN_KINDS", c->tb_chain_kinds);
   c->alpha = 1.0f / (prm.viscosity * prm.dt);  // kernel.cu:182, fp32 at run time
   c->beta = 1.0f / (4.0f + c->alpha);          // kernel.cu:183
   int rc = [&]() -> int {
@@ -925,6 +991,23 @@ static int init_ctx(fluid_ctx **out, const fluid_params *p, int inner_of) {
     HIPCHK(c, hipMalloc(&c->dump, (size_t)prm.n * 16 + 256));
     HIPCHK(c, hipMalloc(&c->halo_flag, 256));
     HIPCHK(c, hipMemsetAsync(c->halo_flag, 0, 256, c->stream));
+    if (c->tb_chain || env_int("FLUID_TB_TRACE", 0)) {
+      tb_chain_capacity(c, &c->chain_words, &c->chain_flags);
+      if (c->chain_words > 0) {
+        const size_t side = (c->chain_words * 8 + 255) & ~(size_t)255, ctl = ((c->chain_flags + 64) * sizeof(int) + 255) & ~(size_t)255;
+        const size_t trace = env_int("FLUID_TB_TRACE", 0) ? c->chain_flags * 4 * sizeof(unsigned long long) : 0;
+        HIPCHK(c, hipMalloc(&c->chain_mem, side + ctl + trace));
+        if (trace) {
+          c->chain.trace = (unsigned long long *)((char *)c->chain_mem + side + ctl);
+          HIPCHK(c, hipMemsetAsync(c->chain.trace, 0, trace, c->stream));
+          c->trace_only.trace = c->chain.trace;
+        }
+        HIPCHK(c, hipMemsetAsync((char *)c->chain_mem + side, 0, ctl, c->stream));  // status word and flags
+        c->chain.side = (unsigned long long *)c->chain_mem;
+        c->chain.status = (int *)((char *)c->chain_mem + side);
+        c->chain.flags = c->chain.status + 64;
+      }
+    }
     if (prm.flags & FLUID_FLAG_VORTICITY) {
       int r = ensure_vort(c);
       if (r) return r;
@@ -960,6 +1043,7 @@ void fluid_destroy(fluid_ctx *c) {
   if (c->vort) (void)hipFree(c->vort);
   if (c->halo_flag) (void)hipFree(c->halo_flag);
   if (c->dump) (void)hipFree(c->dump);
+  if (c->chain_mem) (void)hipFree(c->chain_mem);
   if (c->diag_partial) (void)hipFree(c->diag_partial);
   if (c->cksum) (void)hipFree(c->cksum);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -1066,6 +1150,19 @@ int fluid_debug_sink(fluid_ctx *c, int which, int fill, unsigned pattern, long l
     for (unsigned w : host) d += w != pattern;
     *differing = d;
   }
+  return FLUID_OK;
+}
+
+// Diagnostics (include/fluid.h; FLUID_TB_TRACE=1 at fluid_init): four time stamps per wave of the last
+// temporally blocked launch, record (chunk-row, strip) at out[4 * record]; *words = words written.
+int fluid_debug_chain_trace(fluid_ctx *c, unsigned long long *out, size_t max_words, size_t *words) {
+  if (!c || !out || !words) return FLUID_E_INVALID;
+  if (!c->chain.trace) return FLUID_E_UNSUPPORTED;
+  const size_t n = c->chain_flags * 4 < max_words ? c->chain_flags * 4 : max_words;
+  HIPCHK(c, hipSetDevice(c->prm.device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(out, c->chain.trace, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  *words = n;
   return FLUID_OK;
 }
 

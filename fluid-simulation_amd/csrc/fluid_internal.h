@@ -68,17 +68,30 @@ void launch_add_vorticity(hipStream_t s, Geom g, int r0, int r1, float dt, const
 // streams.  Return false when the shape is unsupported (caller falls back to
 // the straight kernels): n % cols != 0 or k not instantiated.  dump: one row of
 // n * 16 bytes of device memory that receives the rows a wave computes but must not store.
+// Chained chunks: the rows a chunk hands to the chunk above it through memory instead of both
+// computing them (fluid_kernels_tb.hip, Pipe::run).  Device memory of the context: side records
+// (8-byte words), one flag per record (zero between launches), a status word (non-zero: a wave gave up
+// waiting for its neighbour's rows).
+// trace (FLUID_TB_TRACE, diagnostics): null, or 4 shader-clock stamps per record — start, fill done,
+// tail begins, end — of the last chained launch.
+struct TbChain { unsigned long long *side; int *flags; int *status; unsigned long long *trace; };
+bool tb_chain_chunk_ok(int k, int cols, int chunk, int rows);
+int tb_chain_min_chunk(int k);
+int tb_chain_chunk_multiple();
+size_t tb_chain_words(int n, int k, int cols, bool float2_field, int chunks);
+size_t tb_chain_flags(int n, int k, int cols, int chunks);
 bool tb_supported(int n, int cols);
 int tb_resident_blocks(int kind, int k, int cols);  // kind: 0 pressure, 1 divergence + pressure, 2 diffusion
 int tb_blocks_per_row(int n, int k, int cols);
 bool tb_has_k(int k, int cols, bool float2_field);
 bool launch_jacobi_tb(hipStream_t s, Geom g, int r0, int r1, int k, int cols, int chunk,
-                      const float *pin, const float *div, float *pout, void *dump);
+                      const float *pin, const float *div, float *pout, void *dump, const TbChain *chained = nullptr);
 // divergence + p^0 = 0 + the first k Jacobi sweeps in one launch (writes div and p)
 bool launch_jacobi_div_tb(hipStream_t s, Geom g, int r0, int r1, int k, int cols, int chunk,
-                          const float2 *vel, float *div_out, float *pout, void *dump);
+                          const float2 *vel, float *div_out, float *pout, void *dump, const TbChain *chained = nullptr);
 bool launch_diffuse_tb(hipStream_t s, Geom g, int r0, int r1, int k, int cols, int chunk,
-                       float alpha, float beta, const float2 *vin, float2 *vout, void *dump);
+                       float alpha, float beta, const float2 *vin, float2 *vout, void *dump,
+                       const TbChain *chained = nullptr);
 
 // ---- LDS-tiled sweeps for small grids (fluid_kernels_tile.hip) ---------------
 // k sweeps per launch on local rows [r0, r1); false when k is not instantiated.

@@ -54,6 +54,11 @@ constexpr int RING = TB_RING;
 #ifndef TB_RAMP_MINK
 #define TB_RAMP_MINK 8
 #endif
+#ifndef TB_CHAIN_MINK
+#define TB_CHAIN_MINK 10  // chained chunks (Pipe::run) are instantiated from this sweep count up
+#endif
+
+
 
 // value held by lane-1 / lane+1 (DPP wave shift; every lane must be active)
 __device__ __forceinline__ float from_left(float v) {
@@ -166,6 +171,27 @@ __device__ __forceinline__ void store_row2(float2 *p, const Row2<C> &r) {
     reinterpret_cast<float4 *>(p)[c / 2] = make_float4(r.u[c], r.w[c], r.u[c + 1], r.w[c + 1]);
 }
 
+// Rows handed from one chunk to the chunk above it (chained chunks, see Pipe::run): 8-byte words,
+// word w of a lane at q[w * WAVE].  The two chunks run on any two CUs, possibly of two XCDs whose
+// L2s do not snoop each other, so both sides use agent-scope atomics: the store is written through
+// and the load is served from the device's coherence point, neither leaves a line behind in an L2
+// or L1 that the other side cannot see.  (Vector memory instructions; nothing here goes through
+// the scalar cache.)
+typedef unsigned long long u64;
+#ifndef TB_SIDE_PLAIN
+#define TB_SIDE_PLAIN 0  // timing experiments only: 1 = plain stores and loads, 2 = plain stores, 3 = plain loads
+#endif
+__device__ __forceinline__ void side_put(u64 *q, float a, float b) {
+  const u64 v = ((u64)__float_as_uint(b) << 32) | (u64)__float_as_uint(a);
+  if (TB_SIDE_PLAIN == 1 || TB_SIDE_PLAIN == 2) *q = v;
+  else __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void side_get(const u64 *q, float &a, float &b) {
+  const u64 v = (TB_SIDE_PLAIN == 1 || TB_SIDE_PLAIN == 3) ? *q : __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  a = __uint_as_float((unsigned)v);
+  b = __uint_as_float((unsigned)(v >> 32));
+}
+
 // ---------------------------------------------------------------------------
 // Per-row update rules.  apply<XEDGE, YCHK>(a, b, n, d, r, ...) produces row r
 // of the next level from rows r-1 (a), r (b), r+1 (n) of the current level.
@@ -235,6 +261,17 @@ template <int C> struct JacobiOp {
   static __device__ __forceinline__ void store_at(Elem *q, const R &r) { store_row<C>(q, r); }
   static constexpr bool kLoadsField = true;   // level 0 is read from memory
   static constexpr bool kStoresAux = false;   // the auxiliary rows are only read
+  static constexpr int kSideWords = (C + 1) / 2;  // 8-byte words per lane of a row handed to the chunk above
+  static __device__ __forceinline__ void side_store(u64 *q, const R &r) {
+#pragma unroll
+    for (int w = 0; w < kSideWords; ++w) side_put(q + w * WAVE, r.v[2 * w], r.v[C > 1 ? 2 * w + 1 : 0]);
+  }
+  static __device__ __forceinline__ R side_load(const u64 *q) {
+    R r;
+#pragma unroll
+    for (int w = 0; w < kSideWords; ++w) side_get(q + w * WAVE, r.v[2 * w], r.v[C > 1 ? 2 * w + 1 : 0]);
+    return r;
+  }
   // The separate steady-state loop (Pipe::steady_step) costs ~20 VGPRs.  The pressure launches are
   // bound by their memory pattern, not by instruction issue (measured: 0.876 ms with it, 0.866
   // without at 16384^2; 0.086 vs 0.077 at 4096^2 where the registers cost a wave per SIMD).
@@ -255,7 +292,13 @@ template <int C> struct JacobiOp {
       pp.hh(1 - J % 3) = r;
       return r;
     }
-    template <int J, bool YCHK, class PipeT>
+    // the same without the refill (the last RING steps that still need a divergence row)
+    template <int J, class PipeT> __device__ __forceinline__ A cur_last(PipeT &pp) {
+      const A r = apf[J % RING];
+      pp.hh(1 - J % 3) = r;
+      return r;
+    }
+    template <int J, bool YCHK, bool LOAD = true, class PipeT>
     __device__ __forceinline__ void produce(PipeT &, const P &, int, size_t, float *) {}
   };
 
@@ -318,10 +361,22 @@ template <int C> struct DiffuseOp {
   static constexpr bool kLoadsField = true;
   static constexpr bool kStoresAux = false;
   static constexpr bool kSteady = true;  // two planes per column: issue-bound, 1.14 -> 1.06 ms at 16384^2
+  static constexpr int kSideWords = C;  // (u, w) of one column per 8-byte word
+  static __device__ __forceinline__ void side_store(u64 *q, const R &r) {
+#pragma unroll
+    for (int w = 0; w < C; ++w) side_put(q + w * WAVE, r.u[w], r.w[w]);
+  }
+  static __device__ __forceinline__ R side_load(const u64 *q) {
+    R r;
+#pragma unroll
+    for (int w = 0; w < C; ++w) side_get(q + w * WAVE, r.u[w], r.w[w]);
+    return r;
+  }
   template <bool XEDGE> struct Feed {  // no auxiliary field
     template <class PipeT> __device__ __forceinline__ void init(PipeT &, const P &, int) {}
     template <int J, class PipeT> __device__ __forceinline__ A cur(PipeT &, const P &, size_t) { return NoAux{}; }
-    template <int J, bool YCHK, class PipeT>
+    template <int J, class PipeT> __device__ __forceinline__ A cur_last(PipeT &) { return NoAux{}; }
+    template <int J, bool YCHK, bool LOAD = true, class PipeT>
     __device__ __forceinline__ void produce(PipeT &, const P &, int, size_t, float2 *) {}
   };
 
@@ -409,12 +464,14 @@ template <int C> struct JacobiDivOp : JacobiOp<C> {
     template <int J, class PipeT> __device__ __forceinline__ A cur(PipeT &pp, const P &, size_t) {
       return pp.hh(1 - J % 3);
     }
+    template <int J, class PipeT> __device__ __forceinline__ A cur_last(PipeT &pp) { return pp.hh(1 - J % 3); }
     // divergence row t from velocity rows t-1, t, t+1; `voff` addresses velocity row t+1+RING,
     // `dst` is where divergence row t is stored (its real place or the dump row)
-    template <int J, bool YCHK, class PipeT>
+    // (LOAD false: no refill — the tail of a chained chunk, whose last divergence rows are in flight)
+    template <int J, bool YCHK, bool LOAD = true, class PipeT>
     __device__ __forceinline__ void produce(PipeT &pp, const P &p, int t, size_t voff, float *dst) {
       const Row2<C> vc = vpf[J % RING];                 // velocity row t+1
-      vpf[J % RING] = load_row2<C>(p.vel + voff);       // refill the freed slot
+      if constexpr (LOAD) vpf[J % RING] = load_row2<C>(p.vel + voff);  // refill the freed slot
       A d;
       const int N = pp.g.n;
       if (YCHK && (t <= 0 || t >= pp.g.ny - 1)) {  // wave-uniform: border rows, kernel.cu:287
@@ -457,7 +514,7 @@ template <int C> struct JacobiDivOp : JacobiOp<C> {
 // again — and the line shifts by three rows once per group instead of by one
 // row per step (a third of the register moves).
 // ---------------------------------------------------------------------------
-template <class Op, int K, bool XEDGE> struct Pipe {
+template <class Op, int K, bool XEDGE, bool CHAIN = false> struct Pipe {
   using R = typename Op::R;
   using A = typename Op::A;
   using P = typename Op::P;
@@ -470,6 +527,17 @@ template <class Op, int K, bool XEDGE> struct Pipe {
   int x0, xc, ya, yb;  // xc: x0 clamped into the domain (address of this lane's loads)
   bool st_ok;
   XBorder xb;  // meaningful in x-border strips only
+  // chained chunks (CHAIN): this wave's record of side rows and the record of the chunk below it
+  // (same strip), as per-lane pointers; the flags that say a record is complete; which ends of
+  // this chunk are chained (wave-uniform)
+  u64 *side_mine;
+  const u64 *side_below;
+  int *flag_mine, *flag_below, *status;
+  u64 *trace;  // null, or this wave's four time stamps (FLUID_TB_TRACE)
+  bool hands_up, takes_from_below;
+  static constexpr int SIDE_ROW = Op::kSideWords * WAVE;   // 8-byte words of one side row of a strip
+  static constexpr int SIDE_ROWS = 2 * K - 2;              // levels 1 .. K-1, two rows each
+  R sb[CHAIN ? SIDE_ROWS : 1];                             // side rows on their way in (down_step)
 
   __device__ __forceinline__ A &hh(int j) { return h[j + 2]; }
 
@@ -514,11 +582,11 @@ template <class Op, int K, bool XEDGE> struct Pipe {
   }
 
   // LV: levels evaluated (K in the general step; fewer while the pipeline fills, see ramp())
-  template <int J, bool YCHK, int LV = K>
+  template <int J, bool YCHK, int LV = K, int LO = 0>
   __device__ __forceinline__ R levels(const P &p, int t, const A &cur) {
     R fin = Op::zero();
 #pragma unroll
-    for (int l = 0; l < LV; ++l) {
+    for (int l = LO; l < LV; ++l) {
       A d = cur;  // a copy of the value (never a select between two rows' addresses)
       if (l > 0) d = hh(l + 1 - J % 3);
       R o = Op::template apply<XEDGE, YCHK>(s[l][J % 3], s[l][(J + 1) % 3], s[l][(J + 2) % 3], d,
@@ -581,12 +649,87 @@ template <class Op, int K, bool XEDGE> struct Pipe {
         Op::store_at(Op::out_ptr(p, st_ok && ro >= ya && ro < yb, off(ro), (size_t)xc), fin);
       }
     }
+    // chained chunks: level L = JJ / 2 has just produced the first (JJ even) or second (JJ odd) row
+    // of its range; the chunk above ends its level-L range one row short of these two
+    if constexpr (CHAIN && JJ >= 2 && JJ <= 2 * K - 1)
+      Op::side_store(side_mine + (size_t)(JJ - 2) * SIDE_ROW, s[JJ / 2][(J + 2) % 3]);
   }
   template <int JJ, bool YCHK>
   __device__ __forceinline__ void ramp(const P &p, int t0) {
     if constexpr (JJ < RAMP) {
       ramp_step<JJ, YCHK>(p, t0 + JJ);
       ramp<JJ + 1, YCHK>(p, t0);
+    }
+  }
+
+  // Chained chunks, the end of a chunk that has a chunk below it.  Level L of this chunk covers rows
+  // [ya - K + L, yb - K + L): every level R rows, none computed twice.  Its last row needs level
+  // L - 1 two rows further down than level L - 1's own range goes; those are the first two rows of
+  // the range of the chunk below (produced in ITS first steps, ramp_step above) and come in through
+  // memory.  With e = t - (yb - K): level 1 .. K compute while 2L > e, level L = e / 2 takes its row
+  // from the record (e = 2L, 2L + 1: side row e - 2), levels below e / 2 are finished — the mirror
+  // image of ramp().  DOWN0 ordinary steps come first, so that the unrolled tail starts a multiple of
+  // RING steps after t0 when the chunk length is one.
+  //
+  // A side row is a load from the device's coherence point (a microsecond), and the steps get
+  // shorter as levels finish (the last ones are one level: ~100 cycles), so a fixed prefetch
+  // distance in steps would leave the end of every chunk waiting for memory.  The rows are
+  // therefore fetched as early as registers are free for them: a finished level gives back its
+  // three row slots, so B(e) = 3 + 3 * (finished levels - 1) rows may be in flight in step e, and
+  // step e issues every row consumed up to step e + B(e) (all 2K - 2 rows are on their way by
+  // e = K - 2, when more than half the levels still compute).  Straight-line code with compile-time
+  // indices: the allocator puts sb[] into the registers the finished levels leave.
+  static constexpr int DOWN0 = RING;
+  static constexpr int DOWN = DOWN0 + 2 * K;
+  static constexpr int side_issued(int e) {  // side rows fetched by the end of step e
+    if (e < -1) return 0;
+    const int fin = e / 2 - 1 > 0 ? e / 2 - 1 : 0;
+    const int cnt = e + (3 + 3 * fin) - 1;
+    return cnt < 0 ? 0 : cnt > SIDE_ROWS ? SIDE_ROWS : cnt;
+  }
+  template <int M, int M1>
+  __device__ __forceinline__ void side_fetch() {
+    if constexpr (M < M1) {
+      sb[M] = Op::side_load(side_below + (size_t)M * SIDE_ROW);
+      side_fetch<M + 1, M1>();
+    }
+  }
+  template <int EE>
+  __device__ __forceinline__ void down_step(const P &p, int t) {
+    constexpr int J = EE % RING;
+    constexpr int e = EE - DOWN0;
+    constexpr int LO = e < 2 ? 0 : e / 2;   // the level whose row comes in from outside this step
+    if (J % 3 == 0) shift_aux();
+    // The steps shrink as levels finish, and a load that is RING short steps ahead is not ahead at
+    // all: what nobody reads any more is not fetched.  Level l reads the divergence row that came
+    // in l steps earlier, and the levels still computing are l >= e / 2: rows from steps up to
+    // e = K are read (the one of step e - 1 is produced there when the launch computes the
+    // divergence itself), nothing after.
+    A cur = Op::zero_aux();
+    if constexpr (e + RING <= K) cur = feed.template cur<J>(*this, p, off(t - 1 + RING));
+    else if constexpr (e <= K) cur = feed.template cur_last<J>(*this);
+    if constexpr (LO > 0) {
+      s[LO][(J + 2) % 3] = sb[e - 2];
+    } else if constexpr (Op::kLoadsField) {
+      s[0][(J + 2) % 3] = pf[J % RING];
+      if constexpr (e + RING < 2) pf[J % RING] = Op::load(p, off(t + RING));
+    }
+    side_fetch<side_issued(e - 1), side_issued(e)>();
+    if constexpr (Op::kStoresAux && e <= K - 1) {  // divergence rows up to yb - 1
+      const bool areal = st_ok && t >= ya && t < yb;
+      feed.template produce<J, true, (e + RING <= K - 1)>(*this, p, t, off(t + 1 + RING),
+                                                          areal ? p.div_out + off(t) : p.dump + (size_t)g.n + xc);
+    }
+    // every row computed here is y-interior and one this chunk stores (the host only chains
+    // chunks of at least RAMP + 2 * RING rows, tb_chain_chunk_ok)
+    const R fin = levels<J, false, K, LO>(p, t, cur);
+    Op::store_at(Op::out_ptr(p, st_ok, off(t - K), (size_t)xc), fin);
+  }
+  template <int EE>
+  __device__ __forceinline__ void down(const P &p, int td) {
+    if constexpr (EE < DOWN) {
+      down_step<EE>(p, td + EE);
+      down<EE + 1>(p, td);
     }
   }
 
@@ -625,13 +768,22 @@ template <class Op, int K, bool XEDGE> struct Pipe {
     st.ro += n;
   }
 
+  __device__ __forceinline__ void stamp(int i) {
+    if (trace) trace[i] = __builtin_amdgcn_s_memrealtime();  // 100 MHz, one counter for the whole device
+  }
   __device__ __forceinline__ void run(const P &p) {
     const int t0 = ya - K, t1 = yb + K;
+    stamp(0);
     init(p, t0);
     static_assert(RING == 3 || RING == 6, "the time loop is unrolled by a multiple of the slot period");
     // steady window [lo, hi] of steps, then the groups of three that lie inside it
+    // chained at the bottom: the loops end DOWN0 steps before the first step that reads a side row,
+    // a multiple of RING steps after t0 (chunk lengths are multiples of RING then), down() does the rest
+    const bool tail = CHAIN && takes_from_below;
+    const int tend = tail ? yb - K - DOWN0 : t1;
     const int lo = max(ya + K, K + 1);
-    const int hi = min(min((Op::kStoresAux ? yb : yb + K) - 1, g.ny - 1), g.ybase + g.L - 2 - RING);
+    int hi = min(min((Op::kStoresAux ? yb : yb + K) - 1, g.ny - 1), g.ybase + g.L - 2 - RING);
+    if (tail) hi = min(hi, tend - 1);
     const int tsa = t0 + RING * ((lo - t0 + RING - 1) / RING);
     const int tea = hi - (RING - 1) >= tsa ? t0 + RING * ((hi - (RING - 1) - t0) / RING) : tsa - RING;
     Steady st;
@@ -643,8 +795,15 @@ template <class Op, int K, bool XEDGE> struct Pipe {
     // touch no border was measured — nothing at 4096^2 and up, 178 -> 190 us per step at 2048^2,
     // where the extra code costs more than the tests)
     ramp<0, true>(p, t0);
+    if constexpr (CHAIN) {
+      if (hands_up) {  // the record is complete once the stores above have been acknowledged
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(flag_mine, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    stamp(1);
     int t = t0 + RAMP;  // a multiple of RING: the phase of the general loop is unchanged
-    int gend = TB_STEADY && Op::kSteady && tea >= tsa ? min(tsa, t1) : t1;
+    int gend = TB_STEADY && Op::kSteady && tea >= tsa ? min(tsa, tend) : tend;
 #pragma nounroll
     for (int pass = 0; pass < 2; ++pass) {
       for (; t < gend; t += RING) {
@@ -657,7 +816,7 @@ template <class Op, int K, bool XEDGE> struct Pipe {
           step<5>(p, t + 5);
         }
       }
-      if (TB_STEADY && Op::kSteady && pass == 0 && gend < t1) {
+      if (TB_STEADY && Op::kSteady && pass == 0 && gend < tend) {
         for (; t <= tea; t += RING) {
           steady_step<0>(p, t, st);
           steady_step<1>(p, t + 1, st);
@@ -669,14 +828,51 @@ template <class Op, int K, bool XEDGE> struct Pipe {
           }
         }
       }
-      gend = t1;
+      gend = tend;
     }
+    if constexpr (CHAIN) {
+      if (tail) {
+        // The chunk below has a lower workgroup id (tb_kernel_body) and sets the flag after its
+        // first RAMP steps without waiting for anything, so this loop ends; it is bounded anyway
+        // (about a second), because a wave that never ends takes the machine with it: giving up
+        // raises the status word (wrong rows, reported by the host as FLUID_E_DEVICE).  The flag
+        // goes back to 0 for the next launch (one reader per flag).
+        int spins = 0;
+        while (__builtin_amdgcn_readfirstlane(
+                   __hip_atomic_load(flag_below, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) {
+          if (++spins > (1 << 20)) {
+            __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+          __builtin_amdgcn_s_sleep(8);
+        }
+        __hip_atomic_store(flag_below, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        stamp(2);
+        down<0>(p, tend);
+      }
+    }
+    stamp(3);
   }
 };
 
-template <class Op, int K, int C>
+// Where a wave's side records and flags are: record (chunk-row by, strip), nstr strips per chunk-row.
+template <class PipeT>
+__device__ __forceinline__ void chain_setup(PipeT &pipe, TbChain ch, int nstr, int by, int strip, int lane,
+                                            bool chunk_below) {
+  const size_t rec = (size_t)PipeT::SIDE_ROWS * PipeT::SIDE_ROW;  // 8-byte words of one record
+  const int mine = by * nstr + strip;
+  pipe.side_mine = ch.side + (size_t)mine * rec + lane;
+  pipe.side_below = ch.side + (size_t)(mine + nstr) * rec + lane;
+  pipe.flag_mine = ch.flags + mine;
+  pipe.flag_below = ch.flags + mine + nstr;
+  pipe.status = ch.status;
+  pipe.hands_up = by > 0;
+  pipe.takes_from_below = chunk_below;
+}
+
+template <class Op, int K, int C, bool CHAIN = false>
 __device__ __forceinline__ void tb_kernel_body(Geom g, int r0, int r1, int chunk,
-                                               const typename Op::P &p) {
+                                               const typename Op::P &p, TbChain ch = TbChain{}) {
   using SG = StripGeom<K, C>;
   const int lane = threadIdx.x & (WAVE - 1);
   // Workgroups are handed to the 8 XCDs round-robin by linear id.  TB_XCD=1 remaps them so that
@@ -687,8 +883,23 @@ __device__ __forceinline__ void tb_kernel_body(Geom g, int r0, int r1, int chunk
   const int gx = ((g.n + SG::VW - 1) / SG::VW + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
   const int nb = gx * ((r1 - r0 + chunk - 1) / chunk);
   int id = blockIdx.x;
-  if (TB_XCD) id = (id % 8) * ((nb + 7) / 8) + id / 8;
-  if (id >= nb) return;  // whole block: the padding of the grid
+  if constexpr (CHAIN) {
+    // Chained chunks: a chunk waits (once, near its end) for the first steps of the chunk below
+    // it, so the bottom chunk-row takes the lowest workgroup ids: workgroups are handed out in
+    // increasing id (round-robin over the XCDs, in order on each), so whatever a workgroup waits
+    // for belongs to one with a lower id — dispatched before it on its XCD's queue, running or
+    // finished, and itself waiting only for ids lower still: the lowest unfinished id never waits,
+    // so every wait ends.  (A ticket from an atomic counter instead of blockIdx would not need
+    // the dispatch order, and was the first form: 4096 same-address device-scope atomics cost
+    // 36-92 us per launch at 16384^2, more than chaining saves.)  The wait is bounded all the
+    // same (Pipe::run): a wave that gives up raises *ch.status and the host reports it.
+    static_assert(K >= TB_RAMP_MINK && TB_RAMP && C == 2, "chained chunks need the unrolled fill");
+    id = nb - 1 - id;
+    if (id < 0) return;  // whole block: the padding of the grid
+  } else {
+    if (TB_XCD) id = (id % 8) * ((nb + 7) / 8) + id / 8;
+    if (id >= nb) return;  // whole block: the padding of the grid
+  }
   const int bx = id % gx, by = id / gx;
   const int strip = bx * WAVES_PER_BLOCK + (threadIdx.x >> 6);
   const int xs = strip * SG::VW;
@@ -701,43 +912,47 @@ __device__ __forceinline__ void tb_kernel_body(Geom g, int r0, int r1, int chunk
   const int yb = min(ya + chunk, g.ybase + r1);
   const bool xedge = xs == 0 || xs + SG::VW + SG::HX >= g.n;  // wave-uniform
   if (xedge) {
-    Pipe<Op, K, true> pipe;
+    Pipe<Op, K, true, CHAIN> pipe;
     pipe.g = g; pipe.x0 = x0; pipe.xc = xc; pipe.ya = ya; pipe.yb = yb; pipe.st_ok = st_ok;
+    pipe.trace = ch.trace ? ch.trace + (size_t)(by * gx * WAVES_PER_BLOCK + strip) * 4 : nullptr;
     pipe.xb = x_border(x0, g.n);
+    if constexpr (CHAIN) chain_setup(pipe, ch, gx * WAVES_PER_BLOCK, by, strip, lane, yb < g.ybase + r1);
     pipe.run(p);
   } else {
-    Pipe<Op, K, false> pipe;
+    Pipe<Op, K, false, CHAIN> pipe;
     pipe.g = g; pipe.x0 = x0; pipe.xc = xc; pipe.ya = ya; pipe.yb = yb; pipe.st_ok = st_ok;
+    pipe.trace = ch.trace ? ch.trace + (size_t)(by * gx * WAVES_PER_BLOCK + strip) * 4 : nullptr;
     pipe.xb = XBorder{0, 0};
+    if constexpr (CHAIN) chain_setup(pipe, ch, gx * WAVES_PER_BLOCK, by, strip, lane, yb < g.ybase + r1);
     pipe.run(p);
   }
 }
 
-template <int K, int C>
+template <int K, int C, bool CHAIN = false>
 // (Holding the 13-sweep form to 128 VGPRs for a fourth wave per SIMD was tried twice, with
 // __launch_bounds__(256, 4) and amdgpu_waves_per_eu: 7-8 spilled registers, 0.967 -> 1.133 ms
 // per launch at 16384^2.  Left to the register allocator: 132 VGPRs.)
 __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK) void k_jacobi_tb(
     Geom g, int r0, int r1, int chunk, const float *__restrict__ pin,
-    const float *__restrict__ div, float *__restrict__ pout, float *__restrict__ dump) {
+    const float *__restrict__ div, float *__restrict__ pout, float *__restrict__ dump, TbChain ch) {
   typename JacobiOp<C>::P p{pin, div, pout, dump};
-  tb_kernel_body<JacobiOp<C>, K, C>(g, r0, r1, chunk, p);
+  tb_kernel_body<JacobiOp<C>, K, C, CHAIN>(g, r0, r1, chunk, p, ch);
 }
 
-template <int K, int C>
+template <int K, int C, bool CHAIN = false>
 __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK) void k_jacobi_div_tb(
     Geom g, int r0, int r1, int chunk, const float2 *__restrict__ vel, float *__restrict__ div_out,
-    float *__restrict__ pout, float *__restrict__ dump) {
+    float *__restrict__ pout, float *__restrict__ dump, TbChain ch) {
   typename JacobiDivOp<C>::P p{vel, div_out, pout, dump, g.n};
-  tb_kernel_body<JacobiDivOp<C>, K, C>(g, r0, r1, chunk, p);
+  tb_kernel_body<JacobiDivOp<C>, K, C, CHAIN>(g, r0, r1, chunk, p, ch);
 }
 
-template <int K, int C>
+template <int K, int C, bool CHAIN = false>
 __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK) void k_diffuse_tb(
     Geom g, int r0, int r1, int chunk, float alpha, float beta, const float2 *__restrict__ vin,
-    float2 *__restrict__ vout, float2 *__restrict__ dump) {
+    float2 *__restrict__ vout, float2 *__restrict__ dump, TbChain ch) {
   typename DiffuseOp<C>::P p{vin, vout, dump, alpha, beta};
-  tb_kernel_body<DiffuseOp<C>, K, C>(g, r0, r1, chunk, p);
+  tb_kernel_body<DiffuseOp<C>, K, C, CHAIN>(g, r0, r1, chunk, p, ch);
 }
 
 template <int K, int C>
@@ -748,26 +963,43 @@ dim3 tb_grid(Geom g, int r0, int r1, int chunk) {
   return dim3((nb + 7) / 8 * 8);  // see tb_kernel_body: padded so the XCD remap is a bijection
 }
 
+// chained: nullptr, or where the side records, flags and ticket counter of this context are (the
+// caller has checked that the launch fits them, tb_chain_fits)
 template <int K, int C>
 void jacobi_tb_launch(hipStream_t s, Geom g, int r0, int r1, int chunk, const float *pin,
-                      const float *div, float *pout, void *dump) {
-  const dim3 grid = tb_grid<K, C>(g, r0, r1, chunk);
-  k_jacobi_tb<K, C><<<grid, dim3(WAVE * WAVES_PER_BLOCK), 0, s>>>(g, r0, r1, chunk, pin, div, pout,
-                                                                 (float *)dump);
+                      const float *div, float *pout, void *dump, const TbChain *chained) {
+  const dim3 grid = tb_grid<K, C>(g, r0, r1, chunk), block(WAVE * WAVES_PER_BLOCK);
+  if constexpr (C == 2 && K >= TB_CHAIN_MINK && K >= TB_RAMP_MINK) {
+    if (chained && chained->side) {
+      k_jacobi_tb<K, C, true><<<grid, block, 0, s>>>(g, r0, r1, chunk, pin, div, pout, (float *)dump, *chained);
+      return;
+    }
+  }
+  k_jacobi_tb<K, C><<<grid, block, 0, s>>>(g, r0, r1, chunk, pin, div, pout, (float *)dump, chained ? *chained : TbChain{});
 }
 template <int K, int C>
 void jacobi_div_tb_launch(hipStream_t s, Geom g, int r0, int r1, int chunk, const float2 *vel,
-                          float *div_out, float *pout, void *dump) {
-  const dim3 grid = tb_grid<K, C>(g, r0, r1, chunk);
-  k_jacobi_div_tb<K, C><<<grid, dim3(WAVE * WAVES_PER_BLOCK), 0, s>>>(g, r0, r1, chunk, vel, div_out,
-                                                                     pout, (float *)dump);
+                          float *div_out, float *pout, void *dump, const TbChain *chained) {
+  const dim3 grid = tb_grid<K, C>(g, r0, r1, chunk), block(WAVE * WAVES_PER_BLOCK);
+  if constexpr (C == 2 && K >= TB_CHAIN_MINK && K >= TB_RAMP_MINK) {
+    if (chained && chained->side) {
+      k_jacobi_div_tb<K, C, true><<<grid, block, 0, s>>>(g, r0, r1, chunk, vel, div_out, pout, (float *)dump, *chained);
+      return;
+    }
+  }
+  k_jacobi_div_tb<K, C><<<grid, block, 0, s>>>(g, r0, r1, chunk, vel, div_out, pout, (float *)dump, chained ? *chained : TbChain{});
 }
 template <int K, int C>
 void diffuse_tb_launch(hipStream_t s, Geom g, int r0, int r1, int chunk, float alpha, float beta,
-                       const float2 *vin, float2 *vout, void *dump) {
-  const dim3 grid = tb_grid<K, C>(g, r0, r1, chunk);
-  k_diffuse_tb<K, C><<<grid, dim3(WAVE * WAVES_PER_BLOCK), 0, s>>>(g, r0, r1, chunk, alpha, beta, vin,
-                                                                vout, (float2 *)dump);
+                       const float2 *vin, float2 *vout, void *dump, const TbChain *chained) {
+  const dim3 grid = tb_grid<K, C>(g, r0, r1, chunk), block(WAVE * WAVES_PER_BLOCK);
+  if constexpr (C == 2 && K >= TB_CHAIN_MINK && K >= TB_RAMP_MINK) {
+    if (chained && chained->side) {
+      k_diffuse_tb<K, C, true><<<grid, block, 0, s>>>(g, r0, r1, chunk, alpha, beta, vin, vout, (float2 *)dump, *chained);
+      return;
+    }
+  }
+  k_diffuse_tb<K, C><<<grid, block, 0, s>>>(g, r0, r1, chunk, alpha, beta, vin, vout, (float2 *)dump, chained ? *chained : TbChain{});
 }
 
 // Workgroups of one kernel that are resident on the whole device at once (occupancy from the
@@ -827,32 +1059,58 @@ bool tb_has_k(int k, int cols, bool float2_field) {
   }
 }
 
+// Chained chunks (Pipe::run): what a launch must look like, and what it needs in the context's
+// side buffer.  The unrolled tail assumes a chunk length that is a multiple of RING (its phase), a
+// chunk long enough for the fill and the tail not to overlap and for every row of the tail to be
+// one the chunk stores, and somebody to chain to.
+bool tb_chain_chunk_ok(int k, int cols, int chunk, int rows) {
+  const int ramp = (2 * k + RING - 1) / RING * RING;
+  return TB_RAMP && cols == 2 && k >= TB_RAMP_MINK && k >= TB_CHAIN_MINK && chunk % RING == 0 && chunk >= ramp + 2 * RING && rows > chunk;
+}
+int tb_chain_min_chunk(int k) { return (2 * k + RING - 1) / RING * RING + 2 * RING; }
+int tb_chain_chunk_multiple() { return RING; }
+// 8-byte words of side records / flags a launch of `chunks` chunk-rows uses
+size_t tb_chain_words(int n, int k, int cols, bool float2_field, int chunks) {
+  const int nstr = tb_blocks_per_row(n, k, cols) * WAVES_PER_BLOCK;
+  const size_t row = (size_t)(float2_field ? cols : (cols + 1) / 2) * WAVE;
+  return (size_t)chunks * nstr * (2 * k - 2) * row;
+}
+size_t tb_chain_flags(int n, int k, int cols, int chunks) {
+  return (size_t)chunks * tb_blocks_per_row(n, k, cols) * WAVES_PER_BLOCK;
+}
+
 bool launch_jacobi_tb(hipStream_t s, Geom g, int r0, int r1, int k, int cols, int chunk,
-                      const float *pin, const float *div, float *pout, void *dump) {
+                      const float *pin, const float *div, float *pout, void *dump, const TbChain *chained) {
   if (r1 <= r0) return true;
   if (!tb_supported(g.n, cols) || chunk < 1 || !tb_has_k(k, cols, false)) return false;
-  if (cols == 4) TB_DISPATCH_K4(jacobi_tb_launch, s, g, r0, r1, chunk, pin, div, pout, dump)
-  TB_DISPATCH_K2(jacobi_tb_launch, s, g, r0, r1, chunk, pin, div, pout, dump)
-  TB_DISPATCH_K2_DEEP(jacobi_tb_launch, s, g, r0, r1, chunk, pin, div, pout, dump)
+  TbChain plain{};  // not chainable: only the trace pointer goes along
+  if (chained && (!chained->side || !tb_chain_chunk_ok(k, cols, chunk, r1 - r0))) { plain.trace = chained->trace; chained = &plain; }
+  if (cols == 4) TB_DISPATCH_K4(jacobi_tb_launch, s, g, r0, r1, chunk, pin, div, pout, dump, chained)
+  TB_DISPATCH_K2(jacobi_tb_launch, s, g, r0, r1, chunk, pin, div, pout, dump, chained)
+  TB_DISPATCH_K2_DEEP(jacobi_tb_launch, s, g, r0, r1, chunk, pin, div, pout, dump, chained)
   return false;
 }
 
 bool launch_jacobi_div_tb(hipStream_t s, Geom g, int r0, int r1, int k, int cols, int chunk,
-                          const float2 *vel, float *div_out, float *pout, void *dump) {
+                          const float2 *vel, float *div_out, float *pout, void *dump, const TbChain *chained) {
   if (r1 <= r0) return true;
   if (!tb_supported(g.n, cols) || chunk < 1 || !tb_has_k(k, cols, false)) return false;
-  if (cols == 4) TB_DISPATCH_K4(jacobi_div_tb_launch, s, g, r0, r1, chunk, vel, div_out, pout, dump)
-  TB_DISPATCH_K2(jacobi_div_tb_launch, s, g, r0, r1, chunk, vel, div_out, pout, dump)
-  TB_DISPATCH_K2_DEEP(jacobi_div_tb_launch, s, g, r0, r1, chunk, vel, div_out, pout, dump)
+  TbChain plain{};  // not chainable: only the trace pointer goes along
+  if (chained && (!chained->side || !tb_chain_chunk_ok(k, cols, chunk, r1 - r0))) { plain.trace = chained->trace; chained = &plain; }
+  if (cols == 4) TB_DISPATCH_K4(jacobi_div_tb_launch, s, g, r0, r1, chunk, vel, div_out, pout, dump, chained)
+  TB_DISPATCH_K2(jacobi_div_tb_launch, s, g, r0, r1, chunk, vel, div_out, pout, dump, chained)
+  TB_DISPATCH_K2_DEEP(jacobi_div_tb_launch, s, g, r0, r1, chunk, vel, div_out, pout, dump, chained)
   return false;
 }
 
 bool launch_diffuse_tb(hipStream_t s, Geom g, int r0, int r1, int k, int cols, int chunk,
-                       float alpha, float beta, const float2 *vin, float2 *vout, void *dump) {
+                       float alpha, float beta, const float2 *vin, float2 *vout, void *dump, const TbChain *chained) {
   if (r1 <= r0) return true;
   if (!tb_supported(g.n, cols) || chunk < 1 || !tb_has_k(k, cols, true)) return false;
-  if (cols == 4) TB_DISPATCH_K4(diffuse_tb_launch, s, g, r0, r1, chunk, alpha, beta, vin, vout, dump)
-  TB_DISPATCH_K2(diffuse_tb_launch, s, g, r0, r1, chunk, alpha, beta, vin, vout, dump)
+  TbChain plain{};  // not chainable: only the trace pointer goes along
+  if (chained && (!chained->side || !tb_chain_chunk_ok(k, cols, chunk, r1 - r0))) { plain.trace = chained->trace; chained = &plain; }
+  if (cols == 4) TB_DISPATCH_K4(diffuse_tb_launch, s, g, r0, r1, chunk, alpha, beta, vin, vout, dump, chained)
+  TB_DISPATCH_K2(diffuse_tb_launch, s, g, r0, r1, chunk, alpha, beta, vin, vout, dump, chained)
   return false;
 }
 

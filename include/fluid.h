@@ -196,6 +196,14 @@ FLUID_API int fluid_step_noalloc(fluid_ctx *ctx, int nsteps);
  * (Allocates host memory: it is a checker, not a no-allocation entry point.) */
 FLUID_API int fluid_debug_sink(fluid_ctx *ctx, int which, int fill, unsigned pattern, long long *differing);
 
+/* Diagnostics of the temporally blocked launches; no counterpart in the reference.  A context made
+ * with FLUID_TB_TRACE=1 in the environment keeps four time stamps per wave of its last such launch
+ * (device-wide 100 MHz counter: start, pipeline filled, tail begins, end; record (chunk-row, strip)
+ * at out[4 * (chunk-row * strips + strip)], the third stamp only from waves that ran the tail of a
+ * chained chunk, FLUID_TB_CHAIN=1 — DESIGN.md 5.7).  Synchronises; *words = words written, at
+ * most max_words.  FLUID_E_UNSUPPORTED on a context made without FLUID_TB_TRACE. */
+FLUID_API int fluid_debug_chain_trace(fluid_ctx *ctx, unsigned long long *out, size_t max_words, size_t *words);
+
 /* The four stage functions simulationStep() is made of, individually
  * (kernel.cu:542-555, :582-602, :604-662, :664-685) and the optional
  * simulateVorticity() (:557-580).  fluid_step == advect_velocity, diffuse,

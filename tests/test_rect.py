@@ -237,3 +237,47 @@ def test_rect_slabs_equal_whole_domain(pkg, hip, nx, ny, count, J, G):
         assert_bit_equal(group.read(fid), whole.read(fid), f"{f} {nx}x{ny} / {count} slabs")
     group.close()
     whole.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [10, 13, 14])
+@pytest.mark.parametrize("ny,waves", [(600, 100000), (577, 100000), (578, 100000), (612, 100000), (600, 24), (603, 30),
+                                      (431, 18), (300, 100000)])
+def test_chained_chunks_bit_exact(pkg, hip, oracle, k, ny, waves, monkeypatch):
+    """Chained chunks (FLUID_TB_CHAIN, fluid_kernels_tb.hip Pipe::run): a chunk of rows ends its levels
+    one row apart and takes the two rows per level it lacks from the chunk below, which wrote them in
+    its first steps.  Same bits as the sweep-by-sweep oracle for the shortest chunks the host chains
+    (waves = 100000: the minimum length), long ones, a bottom chunk of 1, 2 or a full chunk's rows,
+    x-border strips, both relaxation loops, sweep counts that split into mixed passes, and twice in a
+    row (the flags and the ticket counter must be back at zero after every launch)."""
+    nx, D, J = 600, min(k, 10), 2 * k + 5   # passes of k sweeps (chained) and one of 5 (not instantiated chained)
+    monkeypatch.setenv("FLUID_TB_CHAIN", "1")
+    monkeypatch.setenv("FLUID_TB_CHAIN_KINDS", "7")   # all three kinds of launch (the default chains the pressure launches only)
+    monkeypatch.setenv("FLUID_TILE", "0")
+    monkeypatch.setenv("FLUID_TB_KJ", str(k))
+    monkeypatch.setenv("FLUID_TB_KD", str(min(k, 10)))
+    monkeypatch.setenv("FLUID_TB_MINCHUNK", "0")
+    monkeypatch.setenv("FLUID_TB_WAVES", str(waves))
+    monkeypatch.setenv("FLUID_TB_TRACE", "1")   # time stamps per wave: only the tail of a chained chunk writes the third
+    gpu = pkg.FluidSim(nx, ny=ny, lib=hip, diffusion_iters=D, pressure_iters=J)
+    ref = pkg.FluidSim(nx, ny=ny, lib=oracle, diffusion_iters=D, pressure_iters=J)
+    state = rect_state(nx, ny, seed=k + ny, vmax=30.0)
+    for stage in ("diffuse", "project"):
+        load(gpu, pkg, *state)
+        load(ref, pkg, *state)
+        getattr(gpu, stage)()
+        getattr(ref, stage)()
+        a, b = read_all(gpu, pkg), read_all(ref, pkg)
+        for f in ("velocity", "pressure", "divergence"):
+            assert_bit_equal(a[f], b[f], f"{stage}/{f} k={k} ny={ny} waves={waves}")
+        # the launches really were chained (a launch that does not qualify silently runs unchained)
+        stamps = gpu.chain_trace()
+        assert (stamps[:, 2] != 0).sum() >= 6, f"{stage}: no wave ran the tail of a chained chunk"
+    load(gpu, pkg, *state)
+    load(ref, pkg, *state)
+    for steps in (1, 2):
+        gpu.step(steps)
+        ref.step(steps)
+        a, b = read_all(gpu, pkg), read_all(ref, pkg)
+        for f in FIELDS:
+            assert_bit_equal(a[f], b[f], f"{f} after {steps} more steps, k={k} ny={ny} waves={waves}")
