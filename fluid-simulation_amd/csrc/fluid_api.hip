@@ -107,6 +107,7 @@ struct fluid_ctx {
   int tile_ty = 32;   // rows an LDS tile stores (16 on the smallest grids, see fluid_init)
   bool tile = false;  // small grids: LDS-tiled sweeps (fluid_kernels_tile.hip) instead of the register pipeline
   bool nt_stores = false;  // grids far beyond the caches: non-temporal stores in the two streaming kernels
+  int xcd_run_adv = 0, xcd_run_tail = 0;  // tiles per XCD run in k_advect_vel / k_project_advect_dens (tile_of_block); 0: plain order
   int graph_steps = 1;     // whole steps captured per graph (fluid_step)
   int force_k = 0;           // FLUID_TEST_FORCE_K, see next_pass
   std::vector<int> pass_d, pass_j;  // sweeps of the next launch when `left` diffusion / pressure sweeps remain
@@ -259,7 +260,7 @@ void enq_advect_velocity(fluid_ctx *c, int out_m) {
   {  // [r.r0, band.r0) and [band.r1, r.r1) in one launch; the second range is empty without the band
     ProfScope p(c, K_ADVECT_VEL, 16.0 * cells * ((band.r0 - r.r0) + (r.r1 - band.r1)) / (r.r1 - r.r0));
     launch_advect_vel(c->stream, c->g, r.r0, band.r0, 0, c->g.L, c->prm.dt, c->vel[c->vin],
-                      c->vel[c->vin ^ 1], c->halo_flag, c->nt_stores, band.r1, r.r1);
+                      c->vel[c->vin ^ 1], c->halo_flag, c->nt_stores, c->xcd_run_adv, band.r1, r.r1);
   }
   c->advect_early = false;
   c->vin ^= 1;
@@ -273,7 +274,7 @@ void enq_advect_interior(fluid_ctx *c) {
   if (band.r1 > band.r0) {
     ProfScope p(c, K_ADVECT_VEL, 16.0 * (double)c->g.n * (band.r1 - band.r0));
     launch_advect_vel(c->stream, c->g, band.r0, band.r1, own.r0, own.r1, c->prm.dt, c->vel[c->vin],
-                      c->vel[c->vin ^ 1], c->halo_flag, c->nt_stores);
+                      c->vel[c->vin ^ 1], c->halo_flag, c->nt_stores, c->xcd_run_adv);
   }
   c->advect_early = true;
 }
@@ -559,7 +560,7 @@ void enq_gradient(fluid_ctx *c, bool with_density) {
     const Range valid = c->slab ? widened(c, c->halo_dens) : Range{0, c->g.L};
     launch_project_advect_dens(c->stream, c->g, r.r0, r.r1, valid.r0, valid.r1, c->prm.dt,
                                c->vel[c->vin], c->prs[c->pin], c->vel[c->vin ^ 1], c->dens[c->din],
-                               c->dens[c->din ^ 1], c->halo_flag, c->nt_stores);
+                               c->dens[c->din ^ 1], c->halo_flag, c->nt_stores, c->xcd_run_tail);
     c->vin ^= 1;
     c->din ^= 1;
     return;
@@ -585,7 +586,7 @@ void enq_gradient_density_rows(fluid_ctx *c, bool edges) {
       ProfScope p(c, K_PROJECT_ADVECT_DENS, 60.0 * (double)c->g.n * rows, 52.0 * (double)c->g.n * rows);
       launch_project_advect_dens(c->stream, c->g, own.r0, lo_end, valid.r0, valid.r1, c->prm.dt, c->vel[vi],
                                  c->prs[c->pin], c->vel[vi ^ 1], c->dens[di], c->dens[di ^ 1], c->halo_flag,
-                                 false, hi_beg, own.r1);  // regular stores: the edge rows are packed next
+                                 false, c->xcd_run_tail, hi_beg, own.r1);  // regular stores: the edge rows are packed next
     }
   } else {
     // The interior goes out as a few launches, not one: work queued on another stream meanwhile
@@ -600,7 +601,7 @@ void enq_gradient_density_rows(fluid_ctx *c, bool edges) {
       ProfScope p(c, K_PROJECT_ADVECT_DENS, 60.0 * (double)c->g.n * (r.r1 - r.r0), 52.0 * (double)c->g.n * (r.r1 - r.r0));
       launch_project_advect_dens(c->stream, c->g, r.r0, r.r1, valid.r0, valid.r1, c->prm.dt, c->vel[vi],
                                  c->prs[c->pin], c->vel[vi ^ 1], c->dens[di], c->dens[di ^ 1], c->halo_flag,
-                                 c->nt_stores);
+                                 c->nt_stores, c->xcd_run_tail);
     }
   }
   if (edges) {
@@ -931,6 +932,21 @@ static int init_ctx(fluid_ctx **out, const fluid_params *p, int inner_of) {
   // on from 4.7 M stored cells (round 2: from 2^24; 2560^2 0.240 -> 0.233, 3072^2 0.332 -> 0.326, 3584^2
   // 0.400 -> 0.393; slabs of that size 0-3 % faster).
   // (inner slabs: by the whole domain's size, what the GPU's caches see — 4096^2 as two slabs: 0.525 -> 0.515 ms)
+  // Tile order of the two gather kernels (tile_of_block in fluid_kernels.hip): runs of 128 consecutive tiles per
+  // XCD instead of one, so that x-neighbouring tiles share an L2.  profiles/r03/r3_xcd_sweep*.log, us per launch,
+  // plain order -> runs of 128 (runs of 32 .. 256 are within 2 % of each other; eight whole bands, one per XCD,
+  // win as much up to 4096^2 and lose 6-11 % at 16384^2):
+  //   k_advect_vel            2048^2 24.1 -> 18.5, 3072^2 45.1 -> 36.8, 4096^2 78.3 -> 58.9, 6144^2 150.6 -> 122.7,
+  //                           8192^2 247.6 -> 210.1, 12288^2 517 -> 470, 16384^2 876 -> 807; nothing below 2048^2
+  //   k_project_advect_dens   1280^2 18.0 -> 16.2, 1792^2 31.5 -> 26.4, 2048^2 36.1 -> 33.5, 3072^2 80.5 -> 77.1,
+  //                           4096^2 144.4 -> 139.9; +-1 % from 6144^2 up (its own 16-byte texels dominate): off there
+  {
+    const long long stored = (long long)prm.n * si.store_rows * (inner_of > 0 ? inner_of : 1);
+    c->xcd_run_adv = stored >= (7ll << 19) ? 128 : 0;
+    c->xcd_run_tail = stored >= (3ll << 19) && stored <= (1ll << 25) ? 128 : 0;
+  }
+  c->xcd_run_adv = env_int("FLUID_XCD_RUN_ADV", c->xcd_run_adv);
+  c->xcd_run_tail = env_int("FLUID_XCD_RUN_TAIL", c->xcd_run_tail);
   c->nt_stores = env_int("FLUID_NT", (long long)prm.n * si.store_rows * (inner_of > 0 ? inner_of : 1) >= (9ll << 19) ? 1 : 0) != 0;
   c->graph_steps = env_int("FLUID_GRAPH_STEPS", 16);
   if (c->graph_steps < 1) c->graph_steps = 1;

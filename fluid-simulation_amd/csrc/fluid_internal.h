@@ -42,9 +42,10 @@ extern const char *const kKernelNames[K_COUNT];
 // [vlo, vhi): local rows of the gathered field that hold current data; a
 // backtrace outside raises *halo_flag.
 // nt: non-temporal stores of the output (grids far beyond the caches, see fluid_kernels.hip)
+// xcd_run: 0, or the run of consecutive tiles each XCD takes (tile_of_block in fluid_kernels.hip)
 void launch_copy_block(hipStream_t s, void *dst, const void *src, size_t bytes);  // bytes % 4 == 0
 void launch_advect_vel(hipStream_t s, Geom g, int r0, int r1, int vlo, int vhi, float dt,
-                       const float2 *vin, float2 *vout, int *halo_flag, bool nt, int r0b = 0, int r1b = 0);
+                       const float2 *vin, float2 *vout, int *halo_flag, bool nt, int xcd_run = 0, int r0b = 0, int r1b = 0);
 void launch_diffuse(hipStream_t s, Geom g, int r0, int r1, float alpha, float beta,
                     const float2 *vin, float2 *vout);
 void launch_divergence(hipStream_t s, Geom g, int r0, int r1, const float2 *vel, float *div);
@@ -54,7 +55,7 @@ void launch_project(hipStream_t s, Geom g, int r0, int r1, const float2 *vin, co
                     float2 *vout);
 void launch_project_advect_dens(hipStream_t s, Geom g, int r0, int r1, int vlo, int vhi, float dt,
                                 const float2 *vin, const float *p, float2 *vout, const float4 *din,
-                                float4 *dout, int *flag, bool nt, int r0b = 0, int r1b = 0);
+                                float4 *dout, int *flag, bool nt, int xcd_run = 0, int r0b = 0, int r1b = 0);
 void launch_advect_dens(hipStream_t s, Geom g, int r0, int r1, int vlo, int vhi, float dt,
                         const float2 *vel, const float4 *din, float4 *dout, int *halo_flag);
 void launch_add_force(hipStream_t s, Geom g, int r0, int r1, float dt, float radius, float sx,

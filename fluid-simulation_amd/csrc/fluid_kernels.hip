@@ -145,9 +145,25 @@ __device__ __forceinline__ float2 linear_at_int(const float2 *t, Geom g, int m, 
 constexpr int ADV_ROWS_VEL = ADV_RV;   // measured: 1.33 -> 1.23 ms at 16384^2
 constexpr int ADV_ROWS_DENS = ADV_RD;  // float4 texels: more rows cost occupancy (1.82 -> 2.08 ms with 4)
 
+// Which tile a workgroup takes.  Workgroups go to the 8 XCDs round-robin by linear id, each XCD with an L2 of
+// its own, so with the plain order a tile's x neighbours are always in other L2s and the lines two neighbouring
+// tiles both gather are fetched twice.  run > 0: every XCD takes runs of `run` consecutive tiles instead (within
+// blocks of 8 * run ids: the XCDs still walk the grid together; run < 0: one run each, eight bands); what is left
+// over at the end keeps the plain order.
+__device__ __forceinline__ uint2 tile_of_block(int run) {
+  if (run == 0) return make_uint2(blockIdx.x, blockIdx.y);
+  const unsigned gx = gridDim.x, total = gx * gridDim.y, id = blockIdx.y * gx + blockIdx.x;
+  if (run < 0) run = total / 8 > 0 ? total / 8 : 1;  // one run per XCD: eight contiguous bands of the grid
+  const unsigned span = 8u * run;
+  if (id >= total / span * span) return make_uint2(blockIdx.x, blockIdx.y);
+  const unsigned in = id % span, nid = id - in + (in % 8) * run + in / 8;
+  return make_uint2(nid % gx, nid / gx);
+}
+
 #define ADVECT_PROLOGUE                                        \
-  const int x = blockIdx.x * BX + threadIdx.x;                 \
-  const int rbase = r0 + (blockIdx.y * BY + threadIdx.y) * ADV_ROWS; \
+  const uint2 tile = tile_of_block(xcd_run);                   \
+  const int x = tile.x * BX + threadIdx.x;                     \
+  const int rbase = r0 + (tile.y * BY + threadIdx.y) * ADV_ROWS; \
   if (x >= g.n) return;
 
 // kernel.cu:114-140
@@ -157,7 +173,7 @@ constexpr int ADV_ROWS_DENS = ADV_RD;  // float4 texels: more rows cost occupanc
 template <bool NT, int ADV_ROWS>
 __global__ __launch_bounds__(BX *BY) void k_advect_vel(Geom g, int r0, int r1, Rows second, Valid valid, float dt,
                                                         const float2 *__restrict__ vin,
-                                                        float2 *__restrict__ vout, int *flag) {
+                                                        float2 *__restrict__ vout, int *flag, int xcd_run) {
   if (blockIdx.z) { r0 = second.r0; r1 = second.r1; }  // two row ranges in one launch (slab edges)
   ADVECT_PROLOGUE
   float2 v[ADV_ROWS];
@@ -219,6 +235,7 @@ __global__ __launch_bounds__(BX *BY) void k_advect_dens(Geom g, int r0, int r1, 
                                                          const float4 *__restrict__ din,
                                                          float4 *__restrict__ dout, int *flag) {
   constexpr int ADV_ROWS = ADV_ROWS_DENS;
+  constexpr int xcd_run = 0;
   ADVECT_PROLOGUE
   float2 v[ADV_ROWS];
 #pragma unroll
@@ -346,10 +363,11 @@ template <bool NT>
 __global__ __launch_bounds__(BX *TAIL_BY) void k_project_advect_dens(
     Geom g, int r0, int r1, Rows second, Valid valid, float dt, const float2 *__restrict__ vin,
     const float *__restrict__ p, float2 *__restrict__ vout, const float4 *__restrict__ din,
-    float4 *__restrict__ dout, int *flag) {
+    float4 *__restrict__ dout, int *flag, int xcd_run) {
   if (blockIdx.z) { r0 = second.r0; r1 = second.r1; }  // two row ranges in one launch (slab edges)
-  const int x = blockIdx.x * BX + threadIdx.x;
-  const int r = r0 + blockIdx.y * TAIL_BY + threadIdx.y;
+  const uint2 tile = tile_of_block(xcd_run);
+  const int x = tile.x * BX + threadIdx.x;
+  const int r = r0 + tile.y * TAIL_BY + threadIdx.y;
   if (x >= g.n || r >= r1) return;
   const int y = g.ybase + r;
   const size_t id = (size_t)r * g.n + x;
@@ -451,7 +469,7 @@ void launch_copy_block(hipStream_t s, void *dst, const void *src, size_t bytes) 
 // r0b..r1b: an optional second row range handled by the same launch (the two edges of a slab:
 // two launches of ~10 us each are mostly ramp-up and drain).
 void launch_advect_vel(hipStream_t s, Geom g, int r0, int r1, int vlo, int vhi, float dt,
-                       const float2 *vin, float2 *vout, int *flag, bool nt, int r0b, int r1b) {
+                       const float2 *vin, float2 *vout, int *flag, bool nt, int xcd_run, int r0b, int r1b) {
   if (r1 <= r0) { r0 = r0b; r1 = r1b; r0b = r1b = 0; }
   if (r1 <= r0) return;
   const bool two = r1b > r0b;
@@ -465,13 +483,13 @@ void launch_advect_vel(hipStream_t s, Geom g, int r0, int r1, int vlo, int vhi, 
   }
   if (small)
     hipLaunchKernelGGL((k_advect_vel<false, 1>), grid, kBlock, 0, s, g, r0, r1, Rows{r0b, r1b}, Valid{vlo, vhi}, dt,
-                       vin, vout, flag);
+                       vin, vout, flag, xcd_run);
   else if (nt)
     hipLaunchKernelGGL((k_advect_vel<true, ADV_ROWS_VEL>), grid, kBlock, 0, s, g, r0, r1, Rows{r0b, r1b},
-                       Valid{vlo, vhi}, dt, vin, vout, flag);
+                       Valid{vlo, vhi}, dt, vin, vout, flag, xcd_run);
   else
     hipLaunchKernelGGL((k_advect_vel<false, ADV_ROWS_VEL>), grid, kBlock, 0, s, g, r0, r1, Rows{r0b, r1b},
-                       Valid{vlo, vhi}, dt, vin, vout, flag);
+                       Valid{vlo, vhi}, dt, vin, vout, flag, xcd_run);
 }
 void launch_diffuse(hipStream_t s, Geom g, int r0, int r1, float alpha, float beta,
                     const float2 *vin, float2 *vout) {
@@ -494,17 +512,17 @@ void launch_project(hipStream_t s, Geom g, int r0, int r1, const float2 *vin, co
 }
 void launch_project_advect_dens(hipStream_t s, Geom g, int r0, int r1, int vlo, int vhi, float dt,
                                 const float2 *vin, const float *p, float2 *vout, const float4 *din,
-                                float4 *dout, int *flag, bool nt, int r0b, int r1b) {
+                                float4 *dout, int *flag, bool nt, int xcd_run, int r0b, int r1b) {
   if (r1 <= r0) { r0 = r0b; r1 = r1b; r0b = r1b = 0; }
   if (r1 <= r0) return;
   const int rows = r1b - r0b > r1 - r0 ? r1b - r0b : r1 - r0;
   const dim3 grid((g.n + BX - 1) / BX, (rows + TAIL_BY - 1) / TAIL_BY, r1b > r0b ? 2 : 1), block(BX, TAIL_BY);
   if (nt)
     hipLaunchKernelGGL(k_project_advect_dens<true>, grid, block, 0, s, g, r0, r1, Rows{r0b, r1b}, Valid{vlo, vhi}, dt,
-                       vin, p, vout, din, dout, flag);
+                       vin, p, vout, din, dout, flag, xcd_run);
   else
     hipLaunchKernelGGL(k_project_advect_dens<false>, grid, block, 0, s, g, r0, r1, Rows{r0b, r1b}, Valid{vlo, vhi}, dt,
-                       vin, p, vout, din, dout, flag);
+                       vin, p, vout, din, dout, flag, xcd_run);
 }
 void launch_advect_dens(hipStream_t s, Geom g, int r0, int r1, int vlo, int vhi, float dt,
                         const float2 *vel, const float4 *din, float4 *dout, int *flag) {

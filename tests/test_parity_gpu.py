@@ -437,6 +437,33 @@ def test_pipeline_fill_with_chunks_shorter_and_longer_than_the_fill(pkg, hip, or
             assert_bit_equal(a[f], b[f], f"{f} k={k} chunk={chunk_rows}")
 
 
+@pytest.mark.parametrize("run", [-1, 1, 7, 128, 100000])
+def test_xcd_tile_order_of_the_gather_kernels(pkg, hip, oracle, run, monkeypatch):
+    """The two gather kernels hand their tiles to the XCDs in runs (FLUID_XCD_RUN_ADV / _TAIL; tile_of_block in
+    fluid_kernels.hip): a permutation of the workgroups, so every run length — eight bands, runs that do not divide
+    the grid, runs longer than the grid — gives the oracle's bits, whole steps and single stages, rough data."""
+    monkeypatch.setenv("FLUID_XCD_RUN_ADV", str(run))
+    monkeypatch.setenv("FLUID_XCD_RUN_TAIL", str(run))
+    for n in (200, 1100):
+        gpu, ref = pair(pkg, hip, oracle, n, diffusion_iters=2, pressure_iters=3)
+        state = random_state(n, seed=run + n, vmax=60.0)
+        for stage in ("advect_velocity", "advect_density"):
+            load_state(gpu, pkg, *state)
+            load_state(ref, pkg, *state)
+            getattr(gpu, stage)()
+            getattr(ref, stage)()
+            a, b = read_all(gpu, pkg), read_all(ref, pkg)
+            for f in ("velocity", "density"):
+                assert_bit_equal(a[f], b[f], f"{stage}/{f} n={n} run={run}")
+        load_state(gpu, pkg, *state)
+        load_state(ref, pkg, *state)
+        gpu.step(2)
+        ref.step(2)
+        a, b = read_all(gpu, pkg), read_all(ref, pkg)
+        for f in FIELDS:
+            assert_bit_equal(a[f], b[f], f"{f} n={n} run={run}")
+
+
 @pytest.mark.parametrize("ty", [32, 16])
 @pytest.mark.parametrize("k", [1, 2, 4, 5, 8, 10, 13, 14, 20])   # 13, 14, 20: pressure tiles only
 def test_lds_tiles_bit_exact(pkg, hip, oracle, k, ty, monkeypatch):

@@ -144,7 +144,7 @@ for i in range(nc):
 print(f"C done ({nc} cases), mismatches {bad}", flush=True)
 
 PLAN_ENV = ("FLUID_TB_KJ", "FLUID_TB_KD", "FLUID_TB_CJ", "FLUID_TB_CD", "FLUID_TB_WAVES", "FLUID_TB_MINCHUNK", "FLUID_TILE",
-            "FLUID_TILE_TY", "FLUID_INTERIOR_SPLIT", "FLUID_INTERIOR_PIECE_MIN")
+            "FLUID_TILE_TY", "FLUID_INTERIOR_SPLIT", "FLUID_INTERIOR_PIECE_MIN", "FLUID_TB_CHAIN", "FLUID_TB_CHAIN_KINDS")
 for i in range(nd):
     for k in PLAN_ENV:
         os.environ.pop(k, None)
@@ -152,7 +152,8 @@ for i in range(nd):
            "FLUID_TB_CJ": int(rng.choice([2, 4])), "FLUID_TB_CD": int(rng.choice([2, 4])),
            "FLUID_TB_WAVES": int(rng.choice([1, 7, 64, 500, 2048, 3900, 20000])),
            "FLUID_TB_MINCHUNK": int(rng.integers(1, 5)), "FLUID_TILE": int(rng.integers(0, 2)),
-           "FLUID_TILE_TY": int(rng.choice([16, 32])), "FLUID_INTERIOR_SPLIT": int(rng.integers(1, 9)), "FLUID_INTERIOR_PIECE_MIN": int(rng.choice([1, 5000, 1 << 21]))}
+           "FLUID_TILE_TY": int(rng.choice([16, 32])), "FLUID_INTERIOR_SPLIT": int(rng.integers(1, 9)), "FLUID_INTERIOR_PIECE_MIN": int(rng.choice([1, 5000, 1 << 21])),
+           "FLUID_TB_CHAIN": int(rng.integers(0, 2)), "FLUID_TB_CHAIN_KINDS": int(rng.integers(1, 8))}   # chained chunks
     D, J = int(rng.integers(0, 13)), int(rng.integers(0, 46))
     count = int(rng.integers(1, 5))
     A = int(rng.integers(1, 9))
