@@ -933,7 +933,7 @@ static int init_ctx(fluid_ctx **out, const fluid_params *p, int inner_of) {
   // 0.400 -> 0.393; slabs of that size 0-3 % faster).
   // (inner slabs: by the whole domain's size, what the GPU's caches see — 4096^2 as two slabs: 0.525 -> 0.515 ms)
   // Tile order of the two gather kernels (tile_of_block in fluid_kernels.hip): runs of 128 consecutive tiles per
-  // XCD instead of one, so that x-neighbouring tiles share an L2.  profiles/r03/r3_xcd_sweep*.log, us per launch,
+  // XCD instead of one (64 KB of a row per XCD at a time).  profiles/r03/r3_xcd_sweep*.log, us per launch,
   // plain order -> runs of 128 (runs of 32 .. 256 are within 2 % of each other; eight whole bands, one per XCD,
   // win as much up to 4096^2 and lose 6-11 % at 16384^2):
   //   k_advect_vel            2048^2 24.1 -> 18.5, 3072^2 45.1 -> 36.8, 4096^2 78.3 -> 58.9, 6144^2 150.6 -> 122.7,

@@ -146,10 +146,12 @@ constexpr int ADV_ROWS_VEL = ADV_RV;   // measured: 1.33 -> 1.23 ms at 16384^2
 constexpr int ADV_ROWS_DENS = ADV_RD;  // float4 texels: more rows cost occupancy (1.82 -> 2.08 ms with 4)
 
 // Which tile a workgroup takes.  Workgroups go to the 8 XCDs round-robin by linear id, each XCD with an L2 of
-// its own, so with the plain order a tile's x neighbours are always in other L2s and the lines two neighbouring
-// tiles both gather are fetched twice.  run > 0: every XCD takes runs of `run` consecutive tiles instead (within
-// blocks of 8 * run ids: the XCDs still walk the grid together; run < 0: one run each, eight bands); what is left
-// over at the end keeps the plain order.
+// its own, so with the plain order every XCD touches every 512-byte piece of a row's tiles in turn and a tile's x
+// neighbours (whose gathers overlap its own) are always in other L2s.  run > 0: every XCD takes runs of `run`
+// consecutive tiles of the row-major walk instead — 64 KB of a row at run = 128 — within blocks of 8 * run ids, so
+// the XCDs still walk the grid together (run < 0: one run each, eight bands); what is left over at the end keeps
+// the plain order.  (Runs shaped as 2-D patches of tiles — y neighbours in the same L2 too — were measured: worse
+// than the plain order at every size, profiles/r03/r3_xcd_patch1.log; it is the long contiguous pieces that pay.)
 __device__ __forceinline__ uint2 tile_of_block(int run) {
   if (run == 0) return make_uint2(blockIdx.x, blockIdx.y);
   const unsigned gx = gridDim.x, total = gx * gridDim.y, id = blockIdx.y * gx + blockIdx.x;

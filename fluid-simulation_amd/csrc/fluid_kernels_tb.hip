@@ -880,6 +880,8 @@ __device__ __forceinline__ void tb_kernel_body(Geom g, int r0, int r1, int chunk
   // consecutive chunks share halo rows).  Measured: no difference from 4096^2 up, and 6 % slower
   // at 2048^2 (0.230 vs 0.217 ms per step), where the run of an XCD then holds all of a border's
   // slower waves; off.  (1-D grid of 8 * ceil(blocks / 8) workgroups either way, tb_grid below.)
+  // Round 3: runs of 1 .. 64 consecutive workgroups per XCD, which pay in the gather kernels (tile_of_block in
+  // fluid_kernels.hip): +-0.5 % here at every size (profiles/r03/r3_tb_xcd_run.log).
   const int gx = ((g.n + SG::VW - 1) / SG::VW + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
   const int nb = gx * ((r1 - r0 + chunk - 1) / chunk);
   int id = blockIdx.x;
