@@ -943,7 +943,7 @@ static int init_ctx(fluid_ctx **out, const fluid_params *p, int inner_of) {
   {
     const long long stored = (long long)prm.n * si.store_rows * (inner_of > 0 ? inner_of : 1);
     c->xcd_run_adv = stored >= (7ll << 19) ? 128 : 0;
-    c->xcd_run_tail = stored >= (3ll << 19) && stored <= (1ll << 25) ? 128 : 0;
+    c->xcd_run_tail = stored >= (3ll << 19) && prm.n <= 5120 ? 128 : 0;  // by width: a slab of a wide grid does not gain either (one of 8 of 8192^2, J = 200: 0.871 -> 0.882 ms with it)
   }
   c->xcd_run_adv = env_int("FLUID_XCD_RUN_ADV", c->xcd_run_adv);
   c->xcd_run_tail = env_int("FLUID_XCD_RUN_TAIL", c->xcd_run_tail);
