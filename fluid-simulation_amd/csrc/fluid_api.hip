@@ -107,6 +107,7 @@ struct fluid_ctx {
   int tile_ty = 32;   // rows an LDS tile stores (16 on the smallest grids, see fluid_init)
   bool tile = false;  // small grids: LDS-tiled sweeps (fluid_kernels_tile.hip) instead of the register pipeline
   bool nt_stores = false;  // grids far beyond the caches: non-temporal stores in the two streaming kernels
+  int tb_sync = 0;  // bit per kind of temporally blocked launch (1 pressure, 2 divergence + pressure, 4 diffusion): barriers in the row loops
   int xcd_run_adv = 0, xcd_run_tail = 0;  // tiles per XCD run in k_advect_vel / k_project_advect_dens (tile_of_block); 0: plain order
   int graph_steps = 1;     // whole steps captured per graph (fluid_step)
   int force_k = 0;           // FLUID_TEST_FORCE_K, see next_pass
@@ -367,6 +368,7 @@ TbChain tb_extra(const fluid_ctx *c, int kind, int k, int cols, int chunk, int r
   const int chunks = (rows + chunk - 1) / chunk;
   const bool fits = tb_chain_flags(c->g.n, k, cols, chunks) <= c->chain_flags;
   if (c->trace_only.trace && fits) x.trace = c->trace_only.trace;
+  x.sync = (c->tb_sync >> kind) & 1;
   if (c->tb_chain && ((c->tb_chain_kinds >> kind) & 1) && c->chain_mem && fits && tb_chain_chunk_ok(k, cols, chunk, rows) &&
       tb_chain_words(c->g.n, k, cols, kind == 2, chunks) <= c->chain_words) {
     x.side = c->chain.side;
@@ -945,6 +947,10 @@ static int init_ctx(fluid_ctx **out, const fluid_params *p, int inner_of) {
     c->xcd_run_adv = stored >= (7ll << 19) ? 128 : 0;
     c->xcd_run_tail = stored >= (3ll << 19) && prm.n <= 5120 ? 128 : 0;  // by width: a slab of a wide grid does not gain either (one of 8 of 8192^2, J = 200: 0.871 -> 0.882 ms with it)
   }
+  // barriers in the row loops (fluid_kernels_tb.hip, Pipe::run): the divergence + pressure launch from 2^25 owned
+  // cells, the pressure launches between 2^25 and 2^26 (6144^2 .. 8192^2); never the diffusion launch
+  if (inner_of == 0 && owned >= (1ll << 25)) c->tb_sync = owned <= (1ll << 26) ? 3 : 2;
+  c->tb_sync = env_int("FLUID_TB_SYNC", c->tb_sync);
   c->xcd_run_adv = env_int("FLUID_XCD_RUN_ADV", c->xcd_run_adv);
   c->xcd_run_tail = env_int("FLUID_XCD_RUN_TAIL", c->xcd_run_tail);
   c->nt_stores = env_int("FLUID_NT", (long long)prm.n * si.store_rows * (inner_of > 0 ? inner_of : 1) >= (9ll << 19) ? 1 : 0) != 0;

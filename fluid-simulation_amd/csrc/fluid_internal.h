@@ -75,7 +75,8 @@ void launch_add_vorticity(hipStream_t s, Geom g, int r0, int r1, float dt, const
 // waiting for its neighbour's rows).
 // trace (FLUID_TB_TRACE, diagnostics): null, or 4 shader-clock stamps per record — start, fill done,
 // tail begins, end — of the last chained launch.
-struct TbChain { unsigned long long *side; int *flags; int *status; unsigned long long *trace; };
+// sync: the four waves (strips) of a workgroup meet at a barrier every three rows (Pipe::run)
+struct TbChain { unsigned long long *side; int *flags; int *status; unsigned long long *trace; int sync; };
 bool tb_chain_chunk_ok(int k, int cols, int chunk, int rows);
 int tb_chain_min_chunk(int k);
 int tb_chain_chunk_multiple();

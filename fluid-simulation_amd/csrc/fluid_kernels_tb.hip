@@ -534,6 +534,7 @@ template <class Op, int K, bool XEDGE, bool CHAIN = false> struct Pipe {
   const u64 *side_below;
   int *flag_mine, *flag_below, *status;
   u64 *trace;  // null, or this wave's four time stamps (FLUID_TB_TRACE)
+  bool sync;   // wave-uniform: barriers in the row loops (TbChain::sync)
   bool hands_up, takes_from_below;
   static constexpr int SIDE_ROW = Op::kSideWords * WAVE;   // 8-byte words of one side row of a strip
   static constexpr int SIDE_ROWS = 2 * K - 2;              // levels 1 .. K-1, two rows each
@@ -807,6 +808,13 @@ template <class Op, int K, bool XEDGE, bool CHAIN = false> struct Pipe {
 #pragma nounroll
     for (int pass = 0; pass < 2; ++pass) {
       for (; t < gend; t += RING) {
+        // The four strips of a workgroup kept within RING rows of each other (TbChain::sync): their 4 x 0.5-1 KB
+        // row pieces are adjacent in memory, and on the grids whose launches run for many rounds the waves drift
+        // apart otherwise.  Pays in the divergence + pressure launch, which streams the most bytes per row
+        // (16384^2 1070 -> 1009 us, 8192^2 293 -> 272), a little in the pressure launches at 6144^2-8192^2, costs
+        // the diffusion launch 5 % at 8192^2, nothing anywhere below 6144^2; a barrier every row instead: 1 % worse
+        // (profiles/r03/r3_tb_sync*.log).  Waves that left before the loop (padding strips) are not waited for.
+        if (sync) __builtin_amdgcn_s_barrier();
         step<0>(p, t);
         step<1>(p, t + 1);
         step<2>(p, t + 2);
@@ -818,6 +826,7 @@ template <class Op, int K, bool XEDGE, bool CHAIN = false> struct Pipe {
       }
       if (TB_STEADY && Op::kSteady && pass == 0 && gend < tend) {
         for (; t <= tea; t += RING) {
+          if (sync) __builtin_amdgcn_s_barrier();
           steady_step<0>(p, t, st);
           steady_step<1>(p, t + 1, st);
           steady_step<2>(p, t + 2, st);
@@ -917,6 +926,7 @@ __device__ __forceinline__ void tb_kernel_body(Geom g, int r0, int r1, int chunk
     Pipe<Op, K, true, CHAIN> pipe;
     pipe.g = g; pipe.x0 = x0; pipe.xc = xc; pipe.ya = ya; pipe.yb = yb; pipe.st_ok = st_ok;
     pipe.trace = ch.trace ? ch.trace + (size_t)(by * gx * WAVES_PER_BLOCK + strip) * 4 : nullptr;
+    pipe.sync = ch.sync != 0;
     pipe.xb = x_border(x0, g.n);
     if constexpr (CHAIN) chain_setup(pipe, ch, gx * WAVES_PER_BLOCK, by, strip, lane, yb < g.ybase + r1);
     pipe.run(p);
@@ -924,6 +934,7 @@ __device__ __forceinline__ void tb_kernel_body(Geom g, int r0, int r1, int chunk
     Pipe<Op, K, false, CHAIN> pipe;
     pipe.g = g; pipe.x0 = x0; pipe.xc = xc; pipe.ya = ya; pipe.yb = yb; pipe.st_ok = st_ok;
     pipe.trace = ch.trace ? ch.trace + (size_t)(by * gx * WAVES_PER_BLOCK + strip) * 4 : nullptr;
+    pipe.sync = ch.sync != 0;
     pipe.xb = XBorder{0, 0};
     if constexpr (CHAIN) chain_setup(pipe, ch, gx * WAVES_PER_BLOCK, by, strip, lane, yb < g.ybase + r1);
     pipe.run(p);
@@ -1086,7 +1097,7 @@ bool launch_jacobi_tb(hipStream_t s, Geom g, int r0, int r1, int k, int cols, in
   if (r1 <= r0) return true;
   if (!tb_supported(g.n, cols) || chunk < 1 || !tb_has_k(k, cols, false)) return false;
   TbChain plain{};  // not chainable: only the trace pointer goes along
-  if (chained && (!chained->side || !tb_chain_chunk_ok(k, cols, chunk, r1 - r0))) { plain.trace = chained->trace; chained = &plain; }
+  if (chained && (!chained->side || !tb_chain_chunk_ok(k, cols, chunk, r1 - r0))) { plain.trace = chained->trace; plain.sync = chained->sync; chained = &plain; }
   if (cols == 4) TB_DISPATCH_K4(jacobi_tb_launch, s, g, r0, r1, chunk, pin, div, pout, dump, chained)
   TB_DISPATCH_K2(jacobi_tb_launch, s, g, r0, r1, chunk, pin, div, pout, dump, chained)
   TB_DISPATCH_K2_DEEP(jacobi_tb_launch, s, g, r0, r1, chunk, pin, div, pout, dump, chained)
@@ -1098,7 +1109,7 @@ bool launch_jacobi_div_tb(hipStream_t s, Geom g, int r0, int r1, int k, int cols
   if (r1 <= r0) return true;
   if (!tb_supported(g.n, cols) || chunk < 1 || !tb_has_k(k, cols, false)) return false;
   TbChain plain{};  // not chainable: only the trace pointer goes along
-  if (chained && (!chained->side || !tb_chain_chunk_ok(k, cols, chunk, r1 - r0))) { plain.trace = chained->trace; chained = &plain; }
+  if (chained && (!chained->side || !tb_chain_chunk_ok(k, cols, chunk, r1 - r0))) { plain.trace = chained->trace; plain.sync = chained->sync; chained = &plain; }
   if (cols == 4) TB_DISPATCH_K4(jacobi_div_tb_launch, s, g, r0, r1, chunk, vel, div_out, pout, dump, chained)
   TB_DISPATCH_K2(jacobi_div_tb_launch, s, g, r0, r1, chunk, vel, div_out, pout, dump, chained)
   TB_DISPATCH_K2_DEEP(jacobi_div_tb_launch, s, g, r0, r1, chunk, vel, div_out, pout, dump, chained)
@@ -1110,7 +1121,7 @@ bool launch_diffuse_tb(hipStream_t s, Geom g, int r0, int r1, int k, int cols, i
   if (r1 <= r0) return true;
   if (!tb_supported(g.n, cols) || chunk < 1 || !tb_has_k(k, cols, true)) return false;
   TbChain plain{};  // not chainable: only the trace pointer goes along
-  if (chained && (!chained->side || !tb_chain_chunk_ok(k, cols, chunk, r1 - r0))) { plain.trace = chained->trace; chained = &plain; }
+  if (chained && (!chained->side || !tb_chain_chunk_ok(k, cols, chunk, r1 - r0))) { plain.trace = chained->trace; plain.sync = chained->sync; chained = &plain; }
   if (cols == 4) TB_DISPATCH_K4(diffuse_tb_launch, s, g, r0, r1, chunk, alpha, beta, vin, vout, dump, chained)
   TB_DISPATCH_K2(diffuse_tb_launch, s, g, r0, r1, chunk, alpha, beta, vin, vout, dump, chained)
   return false;

@@ -437,6 +437,25 @@ def test_pipeline_fill_with_chunks_shorter_and_longer_than_the_fill(pkg, hip, or
             assert_bit_equal(a[f], b[f], f"{f} k={k} chunk={chunk_rows}")
 
 
+@pytest.mark.parametrize("k,waves", [(10, 64), (14, 7), (8, 2000), (5, 300)])
+def test_pipeline_with_workgroup_barriers(pkg, hip, oracle, k, waves, monkeypatch):
+    """FLUID_TB_SYNC: the four strips of a workgroup meet at a barrier every three rows (default on the largest
+    grids only).  Same bits with it forced on for every kind of launch, on a grid whose last workgroup has padding
+    strips that leave before the loop, with one and with many chunks per strip."""
+    for name, v in (("FLUID_TB_SYNC", 7), ("FLUID_TILE", 0), ("FLUID_TB_KJ", k), ("FLUID_TB_KD", min(k, 10)), ("FLUID_TB_WAVES", waves)):
+        monkeypatch.setenv(name, str(v))
+    for n in (600, 1000):
+        gpu, ref = pair(pkg, hip, oracle, n, diffusion_iters=min(k, 10) + 1, pressure_iters=2 * k + 3)
+        state = random_state(n, seed=k + n, vmax=30.0)
+        load_state(gpu, pkg, *state)
+        load_state(ref, pkg, *state)
+        gpu.step(2)
+        ref.step(2)
+        a, b = read_all(gpu, pkg), read_all(ref, pkg)
+        for f in FIELDS:
+            assert_bit_equal(a[f], b[f], f"{f} n={n} k={k} waves={waves}")
+
+
 @pytest.mark.parametrize("run", [-1, 1, 7, 128, 100000])
 def test_xcd_tile_order_of_the_gather_kernels(pkg, hip, oracle, run, monkeypatch):
     """The two gather kernels hand their tiles to the XCDs in runs (FLUID_XCD_RUN_ADV / _TAIL; tile_of_block in
