@@ -27,7 +27,13 @@
 namespace {
 
 constexpr int WAVE = 64;
-constexpr int WAVES_PER_BLOCK = 4;
+// Strips (waves) per workgroup.  6 and 12 re-measured in round 3 with and without the row-loop barrier
+// (profiles/r03/r3_tb_wpb.log): 6 breaks the occupancy (4096^2 0.497 -> 0.595 ms), 12 — a whole CU's waves in
+// one workgroup — costs 7 % at 16384^2 and 1 % at 4096^2.
+#ifndef TB_WPB
+#define TB_WPB 4
+#endif
+constexpr int WAVES_PER_BLOCK = TB_WPB;
 // Prefetch ring depth = unroll factor of the time loop (a multiple of 3, the period of the
 // level slots).  Measured on MI355X (tools/ubench/valu_rate.hip): one wave issues a VALU op
 // only every ~8 cycles, and it takes 4-8 waves per SIMD to approach 2.5-3; these pipelines run
