@@ -852,8 +852,9 @@ static const PlanRow kPlan[] = {
     {(1ll << 26) + 1, 14, 10, 6100, 0, 1.f,
      "6144^2 1.197 -> 1.085 ms, 8192^2 1.903 -> 1.826, 8192^2 J=200 4.83 -> 4.43 with one resident round (tools/waves_sweep2.py r2)"},
     {(1ll << 27) + 1, 14, 10, 6100, 0, 0.f, "a slab of 2 of 16384^2: 6100 waves, two rounds (tools/slab_time.py r1)"},
-    {0x7fffffffffffffffll, 14, 10, 16384, 0, 0.f,
-     "12288^2, 16384^2: 16384 waves, shorter chunks even out the end of a launch (tools/plan_sweep.py r1)"},
+    {0x7fffffffffffffffll, 14, 10, 8192, 0, 0.f,
+     "12288^2, 16384^2: r1 16384 waves (shorter chunks even out the end of a launch); r3, with the workgroups of the pressure launches "
+     "kept in step: 8192 waves, 12288^2 3.896 -> 3.843 ms, 16384^2 6.560 -> 6.550 (profiles/r03/r3_waves_resweep.log)"},
 };
 
 // inner_of > 0: the context is one of that many inner slabs of a whole-domain context (inner_init)
