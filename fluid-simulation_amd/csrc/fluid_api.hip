@@ -103,6 +103,7 @@ struct fluid_ctx {
   void *chain_mem = nullptr;
   size_t chain_words = 0, chain_flags = 0;  // capacity: 8-byte words of side records, flags
   bool tile_div = true;    // tile path: the last diffusion launch also writes the divergence (FLUID_TILE_DIV)
+  bool tb_div = true;      // the same on the register-pipeline path (FLUID_TB_DIV): launch_diffuse_div_tb / launch_jacobi0_tb
   bool div_ready = false;  // ... and did, for the projection about to be enqueued
   int tile_ty = 32;   // rows an LDS tile stores (16 on the smallest grids, see fluid_init)
   bool tile = false;  // small grids: LDS-tiled sweeps (fluid_kernels_tile.hip) instead of the register pipeline
@@ -318,8 +319,10 @@ void fill_pass_tables(fluid_ctx *c) {
   for (int l = 1; l <= c->prm.diffusion_iters; ++l) c->pass_d[l] = plan_pass(l, c->tb_kd, c->tile ? 0 : c->tb_cd, true, c->tile);
   for (int l = 1; l <= c->prm.pressure_iters; ++l) c->pass_j[l] = plan_pass(l, c->tb_kj, c->tile ? 0 : c->tb_cj, false, c->tile);
   if (!c->tile && c->tb_rounds > 0.f) {  // ask the runtime for the occupancies now, not while a step is enqueued or captured
-    for (int k : c->pass_d) (void)tb_resident_blocks(2, k, c->tb_cd);
-    for (int k : c->pass_j) { (void)tb_resident_blocks(0, k, c->tb_cj); (void)tb_resident_blocks(1, k, c->tb_cj); }
+    for (int k : c->pass_d) { (void)tb_resident_blocks(2, k, c->tb_cd); (void)tb_resident_blocks(3, k, c->tb_cd); }
+    for (int k : c->pass_j) {
+      (void)tb_resident_blocks(0, k, c->tb_cj); (void)tb_resident_blocks(1, k, c->tb_cj); (void)tb_resident_blocks(4, k, c->tb_cj);
+    }
   }
 }
 
@@ -333,11 +336,12 @@ void fill_pass_tables(fluid_ctx *c) {
 int tb_chunk_count(const fluid_ctx *c, int kind, int k, int cols) {
   int chunks = 0;
   const int resident = c->tb_rounds > 0.f ? tb_resident_blocks(kind, k, cols) : 0;
+  const int kg = kind == 3 ? k + 1 : k;  // strips of the diffusion + divergence launch are laid out for one stage more
   if (resident > 0) {
-    chunks = (int)(c->tb_rounds * resident) / tb_blocks_per_row(c->g.n, k, cols);
+    chunks = (int)(c->tb_rounds * resident) / tb_blocks_per_row(c->g.n, kg, cols);
   } else {
-    const int waves = kind == 2 && c->tb_waves_d > 0 ? c->tb_waves_d : c->tb_waves;
-    const int hx = (k + cols - 1) / cols * cols;
+    const int waves = (kind == 2 || kind == 3) && c->tb_waves_d > 0 ? c->tb_waves_d : c->tb_waves;
+    const int hx = (kg + cols - 1) / cols * cols;
     const int vw = 64 * cols - 2 * hx;
     const int strips = (c->g.n + vw - 1) / vw;
     chunks = waves / strips;
@@ -366,9 +370,10 @@ int tb_chunk(const fluid_ctx *c, int kind, int k, int cols, int rows) {
 TbChain tb_extra(const fluid_ctx *c, int kind, int k, int cols, int chunk, int rows) {
   TbChain x{};
   const int chunks = (rows + chunk - 1) / chunk;
-  const bool fits = tb_chain_flags(c->g.n, k, cols, chunks) <= c->chain_flags;
+  const bool fits = tb_chain_flags(c->g.n, kind == 3 ? k + 1 : k, cols, chunks) <= c->chain_flags;
   if (c->trace_only.trace && fits) x.trace = c->trace_only.trace;
-  x.sync = (c->tb_sync >> kind) & 1;
+  x.sync = (c->tb_sync >> (kind == 3 ? 2 : kind == 4 ? 1 : kind)) & 1;  // 3, 4: as the launches they stand in for
+  if (kind >= 3) return x;
   if (c->tb_chain && ((c->tb_chain_kinds >> kind) & 1) && c->chain_mem && fits && tb_chain_chunk_ok(k, cols, chunk, rows) &&
       tb_chain_words(c->g.n, k, cols, kind == 2, chunks) <= c->chain_words) {
     x.side = c->chain.side;
@@ -423,8 +428,21 @@ void enq_diffuse(fluid_ctx *c, int out_m, bool with_div = false) {
   if (use_tb(c, c->tb_cd)) {
     for (int left = c->prm.diffusion_iters; left > 0;) {
       const int k = next_pass(c, left, true);
-      ProfScope p(c, K_DIFFUSE_TB, 16.0 * k * cells, 16.0 * cells);
       const Range r = widened(c, out_m + left - k);
+      if (with_div && c->tb_div && left == k && tb_has_div_k(k, c->tb_cd)) {
+        // the last pass of a whole step also writes the divergence of its result; the first pressure launch reads
+        // that (c->div_ready) instead of the velocity
+        ProfScope p(c, K_DIFFUSE_TB, 16.0 * k * cells + 12.0 * cells, 20.0 * cells);
+        const int chunk = tb_chunk(c, 3, k, c->tb_cd, r.r1 - r.r0);
+        const TbChain extra = tb_extra(c, 3, k, c->tb_cd, chunk, r.r1 - r.r0);
+        LAUNCH(c, launch_diffuse_div_tb(c->stream, c->g, r.r0, r.r1, k, c->tb_cd, chunk, c->alpha, c->beta, c->vel[c->vin],
+                                     c->vel[c->vin ^ 1], c->div, c->dump, &extra));
+        c->div_ready = true;
+        c->vin ^= 1;
+        left -= k;
+        continue;
+      }
+      ProfScope p(c, K_DIFFUSE_TB, 16.0 * k * cells, 16.0 * cells);
       const int chunk = tb_chunk(c, 2, k, c->tb_cd, r.r1 - r.r0);
       const TbChain extra = tb_extra(c, 2, k, c->tb_cd, chunk, r.r1 - r.r0);
       LAUNCH(c, launch_diffuse_tb(c->stream, c->g, r.r0, r.r1, k, c->tb_cd, chunk, c->alpha, c->beta, c->vel[c->vin],
@@ -508,7 +526,17 @@ void enq_pressure_group(fluid_ctx *c, int g) {
   if (g == 0) {
     // the divergence must cover what every later group's first sweep reads: glen rows beyond
     const int div_m = c->groups > 1 ? glen : -1;
-    if (tb && left > 0) {
+    if (tb && left > 0 && c->div_ready) {
+      // the divergence is in memory (written by the last diffusion launch): resetPressure + the first sweeps
+      const int k = next_pass(c, left, false);
+      ProfScope p(c, K_JACOBI_TB, 12.0 * k * cells, 8.0 * cells);  // divergence in, p out
+      const Range r = widened(c, 1 + left - k);
+      const int chunk = tb_chunk(c, 4, k, c->tb_cj, r.r1 - r.r0);
+      const TbChain extra = tb_extra(c, 4, k, c->tb_cj, chunk, r.r1 - r.r0);
+      LAUNCH(c, launch_jacobi0_tb(c->stream, c->g, r.r0, r.r1, k, c->tb_cj, chunk, c->div, c->prs[c->pin ^ 1], c->dump, &extra));
+      c->pin ^= 1;
+      left -= k;
+    } else if (tb && left > 0) {
       // divergence + resetPressure (p^0 == 0 is a constant, not a buffer) + the first sweeps
       const int k = next_pass(c, left, false);
       ProfScope p(c, K_JACOBI_DIV_TB, 12.0 * cells + 12.0 * k * cells, 16.0 * cells);  // velocity in, divergence and p out
@@ -520,7 +548,7 @@ void enq_pressure_group(fluid_ctx *c, int g) {
       c->pin ^= 1;
       left -= k;
     } else {
-      {
+      if (!c->div_ready) {
         ProfScope p(c, K_DIVERGENCE, 12.0 * cells);
         const Range r = widened(c, div_m >= 0 ? div_m : J);
         launch_divergence(c->stream, c->g, r.r0, r.r1, c->vel[c->vin], c->div);
@@ -529,6 +557,7 @@ void enq_pressure_group(fluid_ctx *c, int g) {
       // other two targets are overwritten before they are read).
       HIPNOTE(c, hipMemsetAsync(c->prs[c->pin], 0, cells_local(c) * sizeof(float), c->stream));
     }
+    c->div_ready = false;
   }
   if (tb) {
     while (left > 0) {
@@ -635,7 +664,7 @@ void enq_velocity_head(fluid_ctx *c) {
   const int m_diff = glen + 1;  // diffused velocity feeds divergence on glen rows
   enq_advect_velocity(c, m_diff + c->prm.diffusion_iters);
   // (vorticity confinement changes the velocity between the two stages; slabs keep the separate form)
-  enq_diffuse(c, m_diff, c->tile_div && !c->slab && !(c->prm.flags & FLUID_FLAG_VORTICITY));
+  enq_diffuse(c, m_diff, (c->tile ? c->tile_div : c->tb_div) && !c->slab && !(c->prm.flags & FLUID_FLAG_VORTICITY));
   if (c->prm.flags & FLUID_FLAG_VORTICITY) enq_vorticity(c);  // kernel.cu:705
   enq_pressure_group(c, 0);
 }
@@ -910,6 +939,7 @@ static int init_ctx(fluid_ctx **out, const fluid_params *p, int inner_of) {
   c->tile_ty = env_int("FLUID_TILE_TY", owned <= 3 * (1ll << 17) ? 16 : 32);
   if (!tile_has_ty(c->tile_ty)) c->tile_ty = 32;
   c->tile_div = env_int("FLUID_TILE_DIV", 1) != 0;
+  c->tb_div = env_int("FLUID_TB_DIV", 1) != 0;
   // (pressure: 14 + 13 + 13 sweeps for J = 40 instead of 4 x 10 — a launch fewer; the taller tiles cost
   // 16.4 us per launch instead of 13.4: 1024^2 81.6 -> 79.2 us per step, 768^2 74.9 -> 73.5, 512^2 J = 40
   // 45.4 -> 43.7.  Two launches of 20 on 104 x 72 tiles lose from 768^2 up: 30.2 us each, 1024^2 92.3.)

@@ -83,7 +83,7 @@ int tb_chain_chunk_multiple();
 size_t tb_chain_words(int n, int k, int cols, bool float2_field, int chunks);
 size_t tb_chain_flags(int n, int k, int cols, int chunks);
 bool tb_supported(int n, int cols);
-int tb_resident_blocks(int kind, int k, int cols);  // kind: 0 pressure, 1 divergence + pressure, 2 diffusion
+int tb_resident_blocks(int kind, int k, int cols);  // kind: 0 pressure, 1 divergence + pressure, 2 diffusion, 3 diffusion + divergence, 4 pressure from p = 0
 int tb_blocks_per_row(int n, int k, int cols);
 bool tb_has_k(int k, int cols, bool float2_field);
 bool launch_jacobi_tb(hipStream_t s, Geom g, int r0, int r1, int k, int cols, int chunk,
@@ -94,6 +94,15 @@ bool launch_jacobi_div_tb(hipStream_t s, Geom g, int r0, int r1, int k, int cols
 bool launch_diffuse_tb(hipStream_t s, Geom g, int r0, int r1, int k, int cols, int chunk,
                        float alpha, float beta, const float2 *vin, float2 *vout, void *dump,
                        const TbChain *chained = nullptr);
+
+// the last diffusion launch of a whole step, also writing the divergence of the field it stores, and the first
+// pressure launch after it (k sweeps from p^0 == 0, the divergence read from memory); strips of the former are
+// laid out for k + 1 sweeps (tb_blocks_per_row(n, k + 1, cols))
+bool tb_has_div_k(int k, int cols);
+bool launch_diffuse_div_tb(hipStream_t s, Geom g, int r0, int r1, int k, int cols, int chunk, float alpha, float beta,
+                           const float2 *vin, float2 *vout, float *div_out, void *dump, const TbChain *extra = nullptr);
+bool launch_jacobi0_tb(hipStream_t s, Geom g, int r0, int r1, int k, int cols, int chunk, const float *div,
+                       float *pout, void *dump, const TbChain *extra = nullptr);
 
 // ---- LDS-tiled sweeps for small grids (fluid_kernels_tile.hip) ---------------
 // k sweeps per launch on local rows [r0, r1); false when k is not instantiated.

@@ -60,6 +60,16 @@ constexpr int RING = TB_RING;
 #ifndef TB_RAMP_MINK
 #define TB_RAMP_MINK 8
 #endif
+// k_diffuse_div_tb<10, 2> holds 172 VGPRs: two waves per SIMD.  Held to three (168 VGPRs, 6 spilled) or without
+// its steady-state loop (158 VGPRs) it is not faster — 16384^2: 1236 us as it is, 1299 / 1293 us those ways,
+// profiles/r03/r3_tb_div_time*.log: the launch takes what its 20 bytes per cell take on this access pattern
+// (the plain diffusion launch: 16 bytes, 963 us), whatever the occupancy.
+#ifndef TB_DIV_WAVES
+#define TB_DIV_WAVES 1  // waves per SIMD the diffusion + divergence launch is held to at least
+#endif
+#ifndef TB_DIV_STEADY
+#define TB_DIV_STEADY 1  // its steady-state loop (20 VGPRs)
+#endif
 #ifndef TB_CHAIN_MINK
 #define TB_CHAIN_MINK 10  // chained chunks (Pipe::run) are instantiated from this sweep count up
 #endif
@@ -267,6 +277,8 @@ template <int C> struct JacobiOp {
   static __device__ __forceinline__ void store_at(Elem *q, const R &r) { store_row<C>(q, r); }
   static constexpr bool kLoadsField = true;   // level 0 is read from memory
   static constexpr bool kStoresAux = false;   // the auxiliary rows are only read
+  static constexpr int kTailRows = 0;  // no stage after the last level (DiffuseDivOp has one)
+  struct Tail {};
   static constexpr int kSideWords = (C + 1) / 2;  // 8-byte words per lane of a row handed to the chunk above
   static __device__ __forceinline__ void side_store(u64 *q, const R &r) {
 #pragma unroll
@@ -367,6 +379,8 @@ template <int C> struct DiffuseOp {
   static constexpr bool kLoadsField = true;
   static constexpr bool kStoresAux = false;
   static constexpr bool kSteady = true;  // two planes per column: issue-bound, 1.14 -> 1.06 ms at 16384^2
+  static constexpr int kTailRows = 0;
+  struct Tail {};
   static constexpr int kSideWords = C;  // (u, w) of one column per 8-byte word
   static __device__ __forceinline__ void side_store(u64 *q, const R &r) {
 #pragma unroll
@@ -418,6 +432,117 @@ template <int C> struct DiffuseOp {
     }
     return o;
   }
+};
+
+// The last diffusion launch of a whole step, which also writes the divergence of the field it stores
+// (kernel.cu:265-289) — one stage more after the last level: divergence row r - 1 from final rows r - 2, r - 1, r
+// as they leave the pipeline.  The first pressure launch then reads 4 bytes of divergence per cell instead of 8
+// of velocity and writes no divergence (JacobiZeroOp): 4 bytes per cell and step less, and the velocity ring of
+// the divergence + pressure launch goes.  The chunk computes one final row more at either end, the strip one
+// column more at either side (kTailRows).
+template <int C> struct DiffuseDivOp : DiffuseOp<C> {
+  using R = Row2<C>;
+  using A = NoAux;
+  using Elem = float2;
+  struct P { const float2 *in; float2 *out; float2 *dump; float alpha, beta; float *div_out; };
+  static __device__ __forceinline__ R load(const P &p, size_t off) { return load_row2<C>(p.in + off); }
+  static __device__ __forceinline__ A load_aux(const P &, size_t) { return NoAux{}; }
+  static __device__ __forceinline__ Elem *out_ptr(const P &p, bool real, size_t off, size_t doff) {
+    return real ? p.out + off : p.dump + doff;
+  }
+  static constexpr int kTailRows = 1;
+  static constexpr bool kSteady = TB_DIV_STEADY;
+  template <bool XEDGE, bool YCHK>
+  static __device__ __forceinline__ R apply(const R &a, const R &b, const R &n, const A &d, int r,
+                                            int x0, int N, int NY, const P &p, XBorder xb) {
+    return DiffuseOp<C>::template apply<XEDGE, YCHK>(a, b, n, d, r, x0, N, NY,
+                                                     typename DiffuseOp<C>::P{nullptr, nullptr, nullptr, p.alpha, p.beta}, xb);
+  }
+  template <bool XEDGE> struct Feed {
+    template <class PipeT> __device__ __forceinline__ void init(PipeT &, const P &, int) {}
+    template <int J, class PipeT> __device__ __forceinline__ A cur(PipeT &, const P &, size_t) { return NoAux{}; }
+    template <int J, class PipeT> __device__ __forceinline__ A cur_last(PipeT &) { return NoAux{}; }
+    template <int J, bool YCHK, bool LOAD = true, class PipeT>
+    __device__ __forceinline__ void produce(PipeT &, const P &, int, size_t, float2 *) {}
+  };
+  struct Tail {
+    R f1;         // final row r - 1
+    float w2[C];  // y-velocity of final row r - 2
+    __device__ __forceinline__ void init() {
+      f1 = zero_row2<C>();
+#pragma unroll
+      for (int c = 0; c < C; ++c) w2[c] = 0.0f;
+    }
+    // fin = final row r; stores the divergence of row r - 1 at dst (its real place or the dump row)
+    template <bool XEDGE, bool YCHK>
+    __device__ __forceinline__ void push(const R &fin, int r, int x0, int N, int NY, float *dst) {
+      Row<C> d;
+      if (YCHK && (r - 1 <= 0 || r - 1 >= NY - 1)) {  // wave-uniform: border rows, kernel.cu:287
+        d = zero_row<C>();
+      } else {
+        const float lu = from_left(f1.u[C - 1]);
+        const float ru = from_right(f1.u[0]);
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          const float uL = c > 0 ? f1.u[c - 1] : lu;
+          const float uR = c < C - 1 ? f1.u[c + 1] : ru;
+          float v = 0.5f * ((uR - uL) + (fin.w[c] - w2[c]));  // kernel.cu:282
+          if (XEDGE) {
+            const int x = x0 + c;
+            if (x == 0 || x == N - 1) v = 0.0f;  // kernel.cu:287
+          }
+          d.v[c] = v;
+        }
+      }
+      store_row<C>(dst, d);
+#pragma unroll
+      for (int c = 0; c < C; ++c) w2[c] = f1.w[c];
+      f1 = fin;
+    }
+  };
+};
+
+// pressureJacobi from p^0 == 0 with the divergence in memory (written by DiffuseDivOp's launch): JacobiOp whose
+// level 0 is the constant zero (as in JacobiDivOp: values the optimiser cannot fold, for the sign of zero).
+template <int C> struct JacobiZeroOp : JacobiOp<C> {
+  using R = Row<C>;
+  struct P { const float *in; const float *aux; float *out; float *dump; };
+  static __device__ __forceinline__ R load(const P &, size_t) {
+    R r;
+#pragma unroll
+    for (int c = 0; c < C; ++c) asm("v_mov_b32 %0, 0" : "=v"(r.v[c]));
+    return r;
+  }
+  static __device__ __forceinline__ Row<C> load_aux(const P &p, size_t off) { return load_row<C>(p.aux + off); }
+  static __device__ __forceinline__ float *out_ptr(const P &p, bool real, size_t off, size_t doff) {
+    return real ? p.out + off : p.dump + doff;
+  }
+  static constexpr bool kLoadsField = false;
+  template <bool XEDGE, bool YCHK>
+  static __device__ __forceinline__ R apply(const R &a, const R &b, const R &n, const Row<C> &d, int r,
+                                            int x0, int N, int NY, const P &, XBorder xb) {
+    return JacobiOp<C>::template apply<XEDGE, YCHK>(a, b, n, d, r, x0, N, NY, typename JacobiOp<C>::P{}, xb);
+  }
+  template <bool XEDGE> struct Feed {  // JacobiOp's, on this P
+    Row<C> apf[RING];
+    template <class PipeT> __device__ __forceinline__ void init(PipeT &pp, const P &p, int t0) {
+#pragma unroll
+      for (int i = 0; i < RING; ++i) apf[i] = load_aux(p, pp.off(t0 - 1 + i));
+    }
+    template <int J, class PipeT> __device__ __forceinline__ Row<C> cur(PipeT &pp, const P &p, size_t aoff) {
+      const Row<C> r = apf[J % RING];
+      apf[J % RING] = load_aux(p, aoff);
+      pp.hh(1 - J % 3) = r;
+      return r;
+    }
+    template <int J, class PipeT> __device__ __forceinline__ Row<C> cur_last(PipeT &pp) {
+      const Row<C> r = apf[J % RING];
+      pp.hh(1 - J % 3) = r;
+      return r;
+    }
+    template <int J, bool YCHK, bool LOAD = true, class PipeT>
+    __device__ __forceinline__ void produce(PipeT &, const P &, int, size_t, float *) {}
+  };
 };
 
 // First projection launch: divergence (kernel.cu:265-289) + resetPressure (kernel.cu:530-540,
@@ -531,6 +656,10 @@ template <class Op, int K, bool XEDGE, bool CHAIN = false> struct Pipe {
   typename Op::template Feed<XEDGE> feed;  // where the auxiliary rows come from
   Geom g;
   int x0, xc, ya, yb;  // xc: x0 clamped into the domain (address of this lane's loads)
+  int st_a, st_b;      // rows this chunk stores: [ya, yb) but for kTailRows rows at either end
+  static constexpr int T = Op::kTailRows;
+  static_assert(!(CHAIN && T > 0), "no chained form of the launch with a stage after the last level");
+  typename Op::Tail tail;
   bool st_ok;
   XBorder xb;  // meaningful in x-border strips only
   // chained chunks (CHAIN): this wave's record of side rows and the record of the chunk below it
@@ -581,6 +710,15 @@ template <class Op, int K, bool XEDGE, bool CHAIN = false> struct Pipe {
       for (int i = 0; i < RING; ++i) pf[i] = Op::load(p, off(t0 + i));
     }
     feed.init(*this, p, t0);
+    if constexpr (T > 0) tail.init();
+  }
+  // the stage after the last level: fin is final row ro; its output is row ro - 1
+  template <bool YCHK>
+  __device__ __forceinline__ void tail_push(const P &p, const R &fin, int ro, float *dst) {
+    tail.template push<XEDGE, YCHK>(fin, ro, x0, g.n, g.ny, dst);
+  }
+  __device__ __forceinline__ float *tail_dst(const P &p, int rd) const {
+    return st_ok && rd >= st_a && rd < st_b ? p.div_out + off(rd) : (float *)p.dump + 2 * (size_t)g.n + xc;
   }
 
   __device__ __forceinline__ void shift_aux() {
@@ -622,7 +760,11 @@ template <class Op, int K, bool XEDGE, bool CHAIN = false> struct Pipe {
     if (t - K >= 1 && t - 1 <= g.ny - 2) fin = levels<J, false>(p, t, cur);  // every level's row is y-interior
     else fin = levels<J, true>(p, t, cur);
     const int ro = t - K;  // level K row just produced
-    Op::store_at(Op::out_ptr(p, st_ok && ro >= ya && ro < yb, off(ro), (size_t)xc), fin);
+    Op::store_at(Op::out_ptr(p, st_ok && ro >= st_a && ro < st_b, off(ro), (size_t)xc), fin);
+    if constexpr (T > 0) {
+      if (ro - 1 >= 1 && ro - 1 <= g.ny - 2) tail_push<false>(p, fin, ro, tail_dst(p, ro - 1));
+      else tail_push<true>(p, fin, ro, tail_dst(p, ro - 1));
+    }
   }
 
   // The first 2K steps of a chunk fill the pipeline: level L is first needed for row ya - (K - L),
@@ -653,7 +795,8 @@ template <class Op, int K, bool XEDGE, bool CHAIN = false> struct Pipe {
       const R fin = levels<J, YCHK, LV>(p, t, cur);
       if constexpr (LV == K) {
         const int ro = t - K;
-        Op::store_at(Op::out_ptr(p, st_ok && ro >= ya && ro < yb, off(ro), (size_t)xc), fin);
+        Op::store_at(Op::out_ptr(p, st_ok && ro >= st_a && ro < st_b, off(ro), (size_t)xc), fin);
+        if constexpr (T > 0) tail_push<YCHK>(p, fin, ro, tail_dst(p, ro - 1));
       }
     }
     // chained chunks: level L = JJ / 2 has just produced the first (JJ even) or second (JJ odd) row
@@ -756,6 +899,8 @@ template <class Op, int K, bool XEDGE, bool CHAIN = false> struct Pipe {
     st.sp = Op::out_ptr(p, st_ok, (size_t)(t - K - g.ybase) * g.n + xc, (size_t)xc);
     st.dp = nullptr;
     if constexpr (Op::kStoresAux) st.dp = st_ok ? p.div_out + st.ro + xc : p.dump + (size_t)g.n + xc;
+    if constexpr (T > 0)  // divergence row t - K - 1
+      st.dp = st_ok ? p.div_out + (size_t)(t - K - 1 - g.ybase) * g.n + xc : (float *)p.dump + 2 * (size_t)g.n + xc;
   }
   template <int J>
   __device__ __forceinline__ void steady_step(const P &p, int t, Steady &st) {
@@ -770,8 +915,9 @@ template <class Op, int K, bool XEDGE, bool CHAIN = false> struct Pipe {
       feed.template produce<J, false>(*this, p, t, st.ro + (RING + 1) * n + (unsigned)xc, st.dp);
     const R fin = levels<J, false>(p, t, cur);
     Op::store_at(st.sp, fin);
+    if constexpr (T > 0) tail_push<false>(p, fin, t - K, st.dp);
     st.sp += st.sstride;
-    if constexpr (Op::kStoresAux) st.dp += st.sstride;
+    if constexpr (Op::kStoresAux || T > 0) st.dp += st.sstride;
     st.ro += n;
   }
 
@@ -788,8 +934,9 @@ template <class Op, int K, bool XEDGE, bool CHAIN = false> struct Pipe {
     // a multiple of RING steps after t0 (chunk lengths are multiples of RING then), down() does the rest
     const bool tail = CHAIN && takes_from_below;
     const int tend = tail ? yb - K - DOWN0 : t1;
-    const int lo = max(ya + K, K + 1);
-    int hi = min(min((Op::kStoresAux ? yb : yb + K) - 1, g.ny - 1), g.ybase + g.L - 2 - RING);
+    // (steady steps store unconditionally: the produced row, and the row of the stage after it, lie in [st_a, st_b))
+    const int lo = max(st_a + T + K, K + 1 + T);
+    int hi = min(min((Op::kStoresAux ? st_b : st_b + K) - 1, g.ny - 1), g.ybase + g.L - 2 - RING);
     if (tail) hi = min(hi, tend - 1);
     const int tsa = t0 + RING * ((lo - t0 + RING - 1) / RING);
     const int tea = hi - (RING - 1) >= tsa ? t0 + RING * ((hi - (RING - 1) - t0) / RING) : tsa - RING;
@@ -888,7 +1035,7 @@ __device__ __forceinline__ void chain_setup(PipeT &pipe, TbChain ch, int nstr, i
 template <class Op, int K, int C, bool CHAIN = false>
 __device__ __forceinline__ void tb_kernel_body(Geom g, int r0, int r1, int chunk,
                                                const typename Op::P &p, TbChain ch = TbChain{}) {
-  using SG = StripGeom<K, C>;
+  using SG = StripGeom<K + Op::kTailRows, C>;
   const int lane = threadIdx.x & (WAVE - 1);
   // Workgroups are handed to the 8 XCDs round-robin by linear id.  TB_XCD=1 remaps them so that
   // each XCD (own L2) works on a contiguous run of blocks (neighbouring strips share halo columns,
@@ -930,7 +1077,8 @@ __device__ __forceinline__ void tb_kernel_body(Geom g, int r0, int r1, int chunk
   const bool xedge = xs == 0 || xs + SG::VW + SG::HX >= g.n;  // wave-uniform
   if (xedge) {
     Pipe<Op, K, true, CHAIN> pipe;
-    pipe.g = g; pipe.x0 = x0; pipe.xc = xc; pipe.ya = ya; pipe.yb = yb; pipe.st_ok = st_ok;
+    pipe.g = g; pipe.x0 = x0; pipe.xc = xc; pipe.st_ok = st_ok;
+    pipe.st_a = ya; pipe.st_b = yb; pipe.ya = ya - Op::kTailRows; pipe.yb = yb + Op::kTailRows;
     pipe.trace = ch.trace ? ch.trace + (size_t)(by * gx * WAVES_PER_BLOCK + strip) * 4 : nullptr;
     pipe.sync = ch.sync != 0;
     pipe.xb = x_border(x0, g.n);
@@ -938,7 +1086,8 @@ __device__ __forceinline__ void tb_kernel_body(Geom g, int r0, int r1, int chunk
     pipe.run(p);
   } else {
     Pipe<Op, K, false, CHAIN> pipe;
-    pipe.g = g; pipe.x0 = x0; pipe.xc = xc; pipe.ya = ya; pipe.yb = yb; pipe.st_ok = st_ok;
+    pipe.g = g; pipe.x0 = x0; pipe.xc = xc; pipe.st_ok = st_ok;
+    pipe.st_a = ya; pipe.st_b = yb; pipe.ya = ya - Op::kTailRows; pipe.yb = yb + Op::kTailRows;
     pipe.trace = ch.trace ? ch.trace + (size_t)(by * gx * WAVES_PER_BLOCK + strip) * 4 : nullptr;
     pipe.sync = ch.sync != 0;
     pipe.xb = XBorder{0, 0};
@@ -972,6 +1121,22 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK) void k_diffuse_tb(
     float2 *__restrict__ vout, float2 *__restrict__ dump, TbChain ch) {
   typename DiffuseOp<C>::P p{vin, vout, dump, alpha, beta};
   tb_kernel_body<DiffuseOp<C>, K, C, CHAIN>(g, r0, r1, chunk, p, ch);
+}
+
+template <int K, int C>
+__global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, TB_DIV_WAVES) void k_diffuse_div_tb(
+    Geom g, int r0, int r1, int chunk, float alpha, float beta, const float2 *__restrict__ vin,
+    float2 *__restrict__ vout, float *__restrict__ div_out, float2 *__restrict__ dump, TbChain ch) {
+  typename DiffuseDivOp<C>::P p{vin, vout, dump, alpha, beta, div_out};
+  tb_kernel_body<DiffuseDivOp<C>, K, C, false>(g, r0, r1, chunk, p, ch);
+}
+
+template <int K, int C>
+__global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK) void k_jacobi0_tb(
+    Geom g, int r0, int r1, int chunk, const float *__restrict__ div, float *__restrict__ pout,
+    float *__restrict__ dump, TbChain ch) {
+  typename JacobiZeroOp<C>::P p{nullptr, div, pout, dump};
+  tb_kernel_body<JacobiZeroOp<C>, K, C, false>(g, r0, r1, chunk, p, ch);
 }
 
 template <int K, int C>
@@ -1021,6 +1186,20 @@ void diffuse_tb_launch(hipStream_t s, Geom g, int r0, int r1, int chunk, float a
   k_diffuse_tb<K, C><<<grid, block, 0, s>>>(g, r0, r1, chunk, alpha, beta, vin, vout, (float2 *)dump, chained ? *chained : TbChain{});
 }
 
+template <int K, int C>
+void diffuse_div_tb_launch(hipStream_t s, Geom g, int r0, int r1, int chunk, float alpha, float beta,
+                           const float2 *vin, float2 *vout, float *div_out, void *dump, const TbChain *extra) {
+  const dim3 grid = tb_grid<K + 1, C>(g, r0, r1, chunk), block(WAVE * WAVES_PER_BLOCK);  // strips one column narrower at either side
+  k_diffuse_div_tb<K, C><<<grid, block, 0, s>>>(g, r0, r1, chunk, alpha, beta, vin, vout, div_out, (float2 *)dump,
+                                                extra ? *extra : TbChain{});
+}
+template <int K, int C>
+void jacobi0_tb_launch(hipStream_t s, Geom g, int r0, int r1, int chunk, const float *div, float *pout, void *dump,
+                       const TbChain *extra) {
+  const dim3 grid = tb_grid<K, C>(g, r0, r1, chunk), block(WAVE * WAVES_PER_BLOCK);
+  k_jacobi0_tb<K, C><<<grid, block, 0, s>>>(g, r0, r1, chunk, div, pout, (float *)dump, extra ? *extra : TbChain{});
+}
+
 // Workgroups of one kernel that are resident on the whole device at once (occupancy from the
 // runtime: registers decide it — 108-112 VGPRs: 4 waves per SIMD, 132-160: 3).
 template <class KernelT>
@@ -1038,6 +1217,8 @@ void resident_blocks_of(KernelT kernel, int *out) {
 template <int K, int C> void jacobi_tb_occ(int *out) { resident_blocks_of(k_jacobi_tb<K, C>, out); }
 template <int K, int C> void jacobi_div_tb_occ(int *out) { resident_blocks_of(k_jacobi_div_tb<K, C>, out); }
 template <int K, int C> void diffuse_tb_occ(int *out) { resident_blocks_of(k_diffuse_tb<K, C>, out); }
+template <int K, int C> void diffuse_div_tb_occ(int *out) { resident_blocks_of(k_diffuse_div_tb<K, C>, out); }
+template <int K, int C> void jacobi0_tb_occ(int *out) { resident_blocks_of(k_jacobi0_tb<K, C>, out); }
 
 }  // namespace
 
@@ -1133,10 +1314,48 @@ bool launch_diffuse_tb(hipStream_t s, Geom g, int r0, int r1, int k, int cols, i
   return false;
 }
 
+// The last diffusion launch of a whole step, also writing the divergence of its result (DiffuseDivOp); the two
+// sweep counts a diffusion plan ends with on the grids that take this path.
+bool tb_has_div_k(int k, int cols) { return cols == 2 && (k == 8 || k == 10); }
+bool launch_diffuse_div_tb(hipStream_t s, Geom g, int r0, int r1, int k, int cols, int chunk, float alpha, float beta,
+                           const float2 *vin, float2 *vout, float *div_out, void *dump, const TbChain *extra) {
+  if (r1 <= r0) return true;
+  if (!tb_supported(g.n, cols) || chunk < 1 || !tb_has_div_k(k, cols)) return false;
+  TbChain plain{};  // never chained: the trace pointer and the barrier flag go along
+  if (extra) { plain.trace = extra->trace; plain.sync = extra->sync; }
+  if (k == 8) diffuse_div_tb_launch<8, 2>(s, g, r0, r1, chunk, alpha, beta, vin, vout, div_out, dump, &plain);
+  else diffuse_div_tb_launch<10, 2>(s, g, r0, r1, chunk, alpha, beta, vin, vout, div_out, dump, &plain);
+  return true;
+}
+// The first pressure launch after it: k sweeps from p^0 == 0 with the divergence read from memory (JacobiZeroOp).
+bool launch_jacobi0_tb(hipStream_t s, Geom g, int r0, int r1, int k, int cols, int chunk, const float *div,
+                       float *pout, void *dump, const TbChain *extra) {
+  if (r1 <= r0) return true;
+  if (!tb_supported(g.n, cols) || chunk < 1 || !tb_has_k(k, cols, false)) return false;
+  TbChain plain{};
+  if (extra) { plain.trace = extra->trace; plain.sync = extra->sync; }
+  extra = &plain;
+  if (cols == 4) TB_DISPATCH_K4(jacobi0_tb_launch, s, g, r0, r1, chunk, div, pout, dump, extra)
+  TB_DISPATCH_K2(jacobi0_tb_launch, s, g, r0, r1, chunk, div, pout, dump, extra)
+  TB_DISPATCH_K2_DEEP(jacobi0_tb_launch, s, g, r0, r1, chunk, div, pout, dump, extra)
+  return false;
+}
+
 // Resident workgroups (4 waves each) of the k-sweep kernel of `kind` (0 pressure, 1 divergence +
 // pressure, 2 diffusion) on the current device; 0 if unknown.  Asked once per kernel.
 namespace {
 bool occ_dispatch(int kind, int k, int cols, int *out) {
+  if (kind == 3) {
+    if (!tb_has_div_k(k, cols)) return false;
+    if (k == 8) diffuse_div_tb_occ<8, 2>(out); else diffuse_div_tb_occ<10, 2>(out);
+    return true;
+  }
+  if (kind == 4) {
+    if (cols == 4) TB_DISPATCH_K4(jacobi0_tb_occ, out)
+    TB_DISPATCH_K2(jacobi0_tb_occ, out)
+    TB_DISPATCH_K2_DEEP(jacobi0_tb_occ, out)
+    return false;
+  }
   if (kind == 2) {
     if (cols == 4) TB_DISPATCH_K4(diffuse_tb_occ, out)
     TB_DISPATCH_K2(diffuse_tb_occ, out)
@@ -1157,10 +1376,10 @@ bool occ_dispatch(int kind, int k, int cols, int *out) {
 int tb_resident_blocks(int kind, int k, int cols) {
   // per device (the answer is the current device's: callers have set the context's), one lock for all
   constexpr int kDevs = 64;
-  static int cache[kDevs][3][16][5];  // 0 = not asked yet, -1 = unknown
+  static int cache[kDevs][5][16][5];  // 0 = not asked yet, -1 = unknown
   static std::mutex mu;
   int dev = 0;
-  if (kind < 0 || kind > 2 || k < 1 || k > 15 || cols < 1 || cols > 4) return 0;
+  if (kind < 0 || kind > 4 || k < 1 || k > 15 || cols < 1 || cols > 4) return 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kDevs) return 0;
   std::lock_guard<std::mutex> lock(mu);
   int &slot = cache[dev][kind][k][cols];

@@ -281,3 +281,34 @@ def test_chained_chunks_bit_exact(pkg, hip, oracle, k, ny, waves, monkeypatch):
         a, b = read_all(gpu, pkg), read_all(ref, pkg)
         for f in FIELDS:
             assert_bit_equal(a[f], b[f], f"{f} after {steps} more steps, k={k} ny={ny} waves={waves}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,J,kd", [(10, 40, 10), (8, 13, 8), (10, 0, 10), (18, 5, 10), (13, 7, 10)])
+@pytest.mark.parametrize("ny,waves", [(600, 64), (333, 100000), (1000, 7)])
+def test_last_diffusion_launch_writes_the_divergence(pkg, hip, oracle, D, J, kd, ny, waves, monkeypatch):
+    """Whole steps on the register-pipeline path: the last diffusion launch also writes the divergence of its result
+    (k_diffuse_div_tb, one stage after the last level) and the first pressure launch starts from p = 0 with the
+    divergence read from memory (k_jacobi0_tb).  Same bits as the sweep-by-sweep oracle — all four fields, the
+    divergence included — for last passes of 10 and 8 sweeps, a last pass that has no such kernel (13 = 10 + 2 + 1:
+    the separate form), J = 0 (no pressure launch to consume it), one and many chunks per strip, x-border strips,
+    and with the fusion switched off."""
+    nx = 600
+    monkeypatch.setenv("FLUID_TILE", "0")
+    monkeypatch.setenv("FLUID_TB_KD", str(kd))
+    monkeypatch.setenv("FLUID_TB_WAVES", str(waves))
+    monkeypatch.setenv("FLUID_TB_MINCHUNK", "0")
+    ref = pkg.FluidSim(nx, ny=ny, lib=oracle, diffusion_iters=D, pressure_iters=J)
+    state = rect_state(nx, ny, seed=D + J + ny, vmax=30.0)
+    load(ref, pkg, *state)
+    ref.step(2)
+    b = read_all(ref, pkg)
+    for fused in ("1", "0"):
+        monkeypatch.setenv("FLUID_TB_DIV", fused)
+        gpu = pkg.FluidSim(nx, ny=ny, lib=hip, diffusion_iters=D, pressure_iters=J)
+        load(gpu, pkg, *state)
+        gpu.step(2)
+        a = read_all(gpu, pkg)
+        for f in FIELDS:
+            assert_bit_equal(a[f], b[f], f"{f} D={D} J={J} ny={ny} waves={waves} FLUID_TB_DIV={fused}")
+        gpu.close()
