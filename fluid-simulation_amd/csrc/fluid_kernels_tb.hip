@@ -153,8 +153,12 @@ __device__ __forceinline__ void store_row(float *p, const Row<C> &r) {
   }
 }
 
+// x halo of a strip: the sweep count rounded to the vector width.  (Rounded up to 16 columns, so that every strip
+// starts on a 128-byte line and stores whole lines: slower everywhere — 16384^2 6.49 -> 6.64 ms, 2048^2 0.169 ->
+// 0.199 — the extra strips cost more than the split lines; profiles/r03/r3_tb_hxalign.log.)
+constexpr int tb_hx(int k, int c) { return (k + c - 1) / c * c; }
 template <int K, int C> struct StripGeom {
-  static constexpr int HX = ((K + C - 1) / C) * C;  // x halo, rounded to the vector width
+  static constexpr int HX = tb_hx(K, C);  // x halo, rounded to the vector width
   static constexpr int VW = WAVE * C - 2 * HX;      // columns a strip produces
   static_assert(VW > 0, "strip too narrow for this K");
 };
@@ -1391,7 +1395,7 @@ int tb_resident_blocks(int kind, int k, int cols) {
 }
 // blocks one chunk-row of the launch has (a workgroup is WAVES_PER_BLOCK strips wide)
 int tb_blocks_per_row(int n, int k, int cols) {
-  const int hx = (k + cols - 1) / cols * cols, vw = WAVE * cols - 2 * hx;
+  const int hx = tb_hx(k, cols), vw = WAVE * cols - 2 * hx;
   const int strips = (n + vw - 1) / vw;
   return (strips + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
 }
