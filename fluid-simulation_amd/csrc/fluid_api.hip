@@ -432,7 +432,7 @@ void enq_diffuse(fluid_ctx *c, int out_m, bool with_div = false) {
       if (with_div && c->tb_div && left == k && tb_has_div_k(k, c->tb_cd)) {
         // the last pass of a whole step also writes the divergence of its result; the first pressure launch reads
         // that (c->div_ready) instead of the velocity
-        ProfScope p(c, K_DIFFUSE_TB, 16.0 * k * cells + 12.0 * cells, 20.0 * cells);
+        ProfScope p(c, K_DIFFUSE_DIV_TB, 16.0 * k * cells + 12.0 * cells, 20.0 * cells);
         const int chunk = tb_chunk(c, 3, k, c->tb_cd, r.r1 - r.r0);
         const TbChain extra = tb_extra(c, 3, k, c->tb_cd, chunk, r.r1 - r.r0);
         LAUNCH(c, launch_diffuse_div_tb(c->stream, c->g, r.r0, r.r1, k, c->tb_cd, chunk, c->alpha, c->beta, c->vel[c->vin],
@@ -529,7 +529,7 @@ void enq_pressure_group(fluid_ctx *c, int g) {
     if (tb && left > 0 && c->div_ready) {
       // the divergence is in memory (written by the last diffusion launch): resetPressure + the first sweeps
       const int k = next_pass(c, left, false);
-      ProfScope p(c, K_JACOBI_TB, 12.0 * k * cells, 8.0 * cells);  // divergence in, p out
+      ProfScope p(c, K_JACOBI0_TB, 12.0 * k * cells, 8.0 * cells);  // divergence in, p out
       const Range r = widened(c, 1 + left - k);
       const int chunk = tb_chunk(c, 4, k, c->tb_cj, r.r1 - r.r0);
       const TbChain extra = tb_extra(c, 4, k, c->tb_cj, chunk, r.r1 - r.r0);

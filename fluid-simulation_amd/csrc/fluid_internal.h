@@ -32,6 +32,8 @@ enum KernelId {
   K_DIFFUSE_TILE,         // LDS-tiled sweeps for small grids (fluid_kernels_tile.hip)
   K_JACOBI_TILE,
   K_JACOBI_DIV_TILE,
+  K_DIFFUSE_DIV_TB,  // the last diffusion launch of a whole step, also writing the divergence
+  K_JACOBI0_TB,      // the first pressure launch after it: from p = 0, the divergence read from memory
   K_COUNT
 };
 extern const char *const kKernelNames[K_COUNT];

@@ -19,7 +19,7 @@
 const char *const kKernelNames[K_COUNT] = {
     "k_advect_vel", "k_diffuse",   "k_divergence",    "k_jacobi",     "k_project", "k_advect_dens",
     "k_add_force",  "k_vorticity", "k_add_vorticity", "k_diffuse_tb", "k_jacobi_tb", "k_jacobi_div_tb",
-    "k_project_advect_dens", "k_diffuse_tile", "k_jacobi_tile", "k_jacobi_div_tile"};
+    "k_project_advect_dens", "k_diffuse_tile", "k_jacobi_tile", "k_jacobi_div_tile", "k_diffuse_div_tb", "k_jacobi0_tb"};
 
 namespace {
 
