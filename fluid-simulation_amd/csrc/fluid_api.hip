@@ -108,6 +108,7 @@ struct fluid_ctx {
   int tile_ty = 32;   // rows an LDS tile stores (16 on the smallest grids, see fluid_init)
   bool tile = false;  // small grids: LDS-tiled sweeps (fluid_kernels_tile.hip) instead of the register pipeline
   bool nt_stores = false;  // grids far beyond the caches: non-temporal stores in the two streaming kernels
+  float tb_j0_share = 1.f;  // share of a resident round the first pressure launch from p = 0 is sized to (it holds four waves per SIMD)
   int tb_sync = 0;  // bit per kind of temporally blocked launch (1 pressure, 2 divergence + pressure, 4 diffusion): barriers in the row loops
   int xcd_run_adv = 0, xcd_run_tail = 0;  // tiles per XCD run in k_advect_vel / k_project_advect_dens (tile_of_block); 0: plain order
   int graph_steps = 1;     // whole steps captured per graph (fluid_step)
@@ -338,7 +339,7 @@ int tb_chunk_count(const fluid_ctx *c, int kind, int k, int cols) {
   const int resident = c->tb_rounds > 0.f ? tb_resident_blocks(kind, k, cols) : 0;
   const int kg = kind == 3 ? k + 1 : k;  // strips of the diffusion + divergence launch are laid out for one stage more
   if (resident > 0) {
-    chunks = (int)(c->tb_rounds * resident) / tb_blocks_per_row(c->g.n, kg, cols);
+    chunks = (int)(c->tb_rounds * resident * (kind == 4 ? c->tb_j0_share : 1.f)) / tb_blocks_per_row(c->g.n, kg, cols);
   } else {
     const int waves = (kind == 2 || kind == 3) && c->tb_waves_d > 0 ? c->tb_waves_d : c->tb_waves;
     const int hx = (kg + cols - 1) / cols * cols;
@@ -981,6 +982,11 @@ static int init_ctx(fluid_ctx **out, const fluid_params *p, int inner_of) {
   // barriers in the row loops (fluid_kernels_tb.hip, Pipe::run): the divergence + pressure launch from 2^25 owned
   // cells, the pressure launches between 2^25 and 2^26 (6144^2 .. 8192^2); never the diffusion launch
   if (inner_of == 0 && owned >= (1ll << 25)) c->tb_sync = owned <= (1ll << 26) ? 3 : 2;
+  // the first pressure launch from p = 0 (k_jacobi0_tb) holds four waves per SIMD where the other pressure launches
+  // hold three; at 3072^2 .. 4096^2 it does better at three quarters of its resident round (chunks as long as
+  // theirs): 4096^2 74.5 -> 70.7 us, 3072^2 52.2 -> 49.3; a full round from 6144^2 up (profiles/r03/r3_j0_share.log)
+  if (inner_of == 0 && owned >= (1ll << 23) && owned <= (1ll << 24)) c->tb_j0_share = 0.75f;
+  c->tb_j0_share = env_int("FLUID_TB_J0_PCT", (int)(c->tb_j0_share * 100.f + 0.5f)) / 100.f;
   c->tb_sync = env_int("FLUID_TB_SYNC", c->tb_sync);
   c->xcd_run_adv = env_int("FLUID_XCD_RUN_ADV", c->xcd_run_adv);
   c->xcd_run_tail = env_int("FLUID_XCD_RUN_TAIL", c->xcd_run_tail);
