@@ -664,8 +664,10 @@ void enq_velocity_head(fluid_ctx *c) {
   const int glen = c->groups > 1 ? c->jg : c->prm.pressure_iters;
   const int m_diff = glen + 1;  // diffused velocity feeds divergence on glen rows
   enq_advect_velocity(c, m_diff + c->prm.diffusion_iters);
-  // (vorticity confinement changes the velocity between the two stages; slabs keep the separate form)
-  enq_diffuse(c, m_diff, (c->tile ? c->tile_div : c->tb_div) && !c->slab && !(c->prm.flags & FLUID_FLAG_VORTICITY));
+  // (vorticity confinement changes the velocity between the two stages.  Slabs: the pipeline path's fused launch
+  // covers widened(glen + 1) and its divergence is good one row inside that — widened(glen), all any pressure
+  // launch reads; the tile path keeps the separate form there)
+  enq_diffuse(c, m_diff, (c->tile ? c->tile_div && !c->slab : c->tb_div) && !(c->prm.flags & FLUID_FLAG_VORTICITY));
   if (c->prm.flags & FLUID_FLAG_VORTICITY) enq_vorticity(c);  // kernel.cu:705
   enq_pressure_group(c, 0);
 }
