@@ -1253,6 +1253,18 @@ template <int K, int C> void jacobi0_tb_occ(int *out) { resident_blocks_of(k_jac
     default: break;                                  \
   }
 
+// The instantiations are split over three translation units so that they compile side by side (the Makefile
+// builds this file three times, -DTB_PART=0 / 1 / 2; without TB_PART everything is emitted, as the ISA test wants):
+// part 0 the pressure launches and the helpers, part 1 the two first-pressure-launch forms, part 2 the diffusion ones.
+#ifdef TB_PART
+#define TB_IN_PART(n) (TB_PART == (n))
+#else
+#define TB_IN_PART(n) 1
+#endif
+bool tb_occ_part1(int kind, int k, int cols, int *out);
+bool tb_occ_part2(int kind, int k, int cols, int *out);
+
+#if TB_IN_PART(0)
 bool tb_supported(int n, int cols) { return (cols == 2 || cols == 4) && n % cols == 0 && n >= 8; }
 bool tb_has_k(int k, int cols, bool float2_field) {
   switch (k) {
@@ -1295,6 +1307,8 @@ bool launch_jacobi_tb(hipStream_t s, Geom g, int r0, int r1, int k, int cols, in
   return false;
 }
 
+#endif  // part 0
+#if TB_IN_PART(1)
 bool launch_jacobi_div_tb(hipStream_t s, Geom g, int r0, int r1, int k, int cols, int chunk,
                           const float2 *vel, float *div_out, float *pout, void *dump, const TbChain *chained) {
   if (r1 <= r0) return true;
@@ -1307,6 +1321,8 @@ bool launch_jacobi_div_tb(hipStream_t s, Geom g, int r0, int r1, int k, int cols
   return false;
 }
 
+#endif  // part 1
+#if TB_IN_PART(2)
 bool launch_diffuse_tb(hipStream_t s, Geom g, int r0, int r1, int k, int cols, int chunk,
                        float alpha, float beta, const float2 *vin, float2 *vout, void *dump, const TbChain *chained) {
   if (r1 <= r0) return true;
@@ -1331,6 +1347,18 @@ bool launch_diffuse_div_tb(hipStream_t s, Geom g, int r0, int r1, int k, int col
   else diffuse_div_tb_launch<10, 2>(s, g, r0, r1, chunk, alpha, beta, vin, vout, div_out, dump, &plain);
   return true;
 }
+bool tb_occ_part2(int kind, int k, int cols, int *out) {
+  if (kind == 3) {
+    if (!tb_has_div_k(k, cols)) return false;
+    if (k == 8) diffuse_div_tb_occ<8, 2>(out); else diffuse_div_tb_occ<10, 2>(out);
+    return true;
+  }
+  if (cols == 4) TB_DISPATCH_K4(diffuse_tb_occ, out)
+  TB_DISPATCH_K2(diffuse_tb_occ, out)
+  return false;
+}
+#endif  // part 2
+#if TB_IN_PART(1)
 // The first pressure launch after it: k sweeps from p^0 == 0 with the divergence read from memory (JacobiZeroOp).
 bool launch_jacobi0_tb(hipStream_t s, Geom g, int r0, int r1, int k, int cols, int chunk, const float *div,
                        float *pout, void *dump, const TbChain *extra) {
@@ -1345,32 +1373,27 @@ bool launch_jacobi0_tb(hipStream_t s, Geom g, int r0, int r1, int k, int cols, i
   return false;
 }
 
-// Resident workgroups (4 waves each) of the k-sweep kernel of `kind` (0 pressure, 1 divergence +
-// pressure, 2 diffusion) on the current device; 0 if unknown.  Asked once per kernel.
-namespace {
-bool occ_dispatch(int kind, int k, int cols, int *out) {
-  if (kind == 3) {
-    if (!tb_has_div_k(k, cols)) return false;
-    if (k == 8) diffuse_div_tb_occ<8, 2>(out); else diffuse_div_tb_occ<10, 2>(out);
-    return true;
-  }
+bool tb_occ_part1(int kind, int k, int cols, int *out) {
   if (kind == 4) {
     if (cols == 4) TB_DISPATCH_K4(jacobi0_tb_occ, out)
     TB_DISPATCH_K2(jacobi0_tb_occ, out)
     TB_DISPATCH_K2_DEEP(jacobi0_tb_occ, out)
     return false;
   }
-  if (kind == 2) {
-    if (cols == 4) TB_DISPATCH_K4(diffuse_tb_occ, out)
-    TB_DISPATCH_K2(diffuse_tb_occ, out)
-    return false;
-  }
-  if (kind == 1) {
-    if (cols == 4) TB_DISPATCH_K4(jacobi_div_tb_occ, out)
-    TB_DISPATCH_K2(jacobi_div_tb_occ, out)
-    TB_DISPATCH_K2_DEEP(jacobi_div_tb_occ, out)
-    return false;
-  }
+  if (cols == 4) TB_DISPATCH_K4(jacobi_div_tb_occ, out)
+  TB_DISPATCH_K2(jacobi_div_tb_occ, out)
+  TB_DISPATCH_K2_DEEP(jacobi_div_tb_occ, out)
+  return false;
+}
+#endif  // part 1
+#if TB_IN_PART(0)
+// Resident workgroups (4 waves each) of the k-sweep kernel of `kind` (0 pressure, 1 divergence + pressure,
+// 2 diffusion, 3 diffusion + divergence, 4 pressure from p = 0) on the current device; 0 if unknown.  Asked
+// once per kernel.
+namespace {
+bool occ_dispatch(int kind, int k, int cols, int *out) {
+  if (kind == 2 || kind == 3) return tb_occ_part2(kind, k, cols, out);
+  if (kind == 1 || kind == 4) return tb_occ_part1(kind, k, cols, out);
   if (cols == 4) TB_DISPATCH_K4(jacobi_tb_occ, out)
   TB_DISPATCH_K2(jacobi_tb_occ, out)
   TB_DISPATCH_K2_DEEP(jacobi_tb_occ, out)
@@ -1399,3 +1422,4 @@ int tb_blocks_per_row(int n, int k, int cols) {
   const int strips = (n + vw - 1) / vw;
   return (strips + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
 }
+#endif  // part 0
