@@ -200,10 +200,11 @@ class FluidLib:
         return msg.value.decode()
 
     def slab_plan(self, n, slab_rank, slab_count, *, diffusion_iters=None, pressure_iters=None,
-                  halo_rows=0, pressure_groups=0, ny=0) -> dict:
+                  halo_rows=0, pressure_groups=0, ny=0, flags=0) -> dict:
         """fluid_slab_plan: pure host arithmetic, needs no GPU."""
         p = self.default_params()
         p.n, p.slab_rank, p.slab_count, p.halo_rows = n, slab_rank, slab_count, halo_rows
+        p.flags = flags   # FLAG_VORTICITY deepens the velocity halo by two rows
         p.pressure_groups = pressure_groups
         p.ny = ny
         if diffusion_iters is not None:
@@ -291,7 +292,7 @@ class FluidSim:
         if slab_count > 1 and pressure_groups > 1:
             self.pressure_groups = self.lib.slab_plan(
                 self.n, slab_rank, slab_count, diffusion_iters=p.diffusion_iters, pressure_iters=p.pressure_iters,
-                halo_rows=halo_rows, pressure_groups=pressure_groups, ny=ny)["pressure_groups"]
+                halo_rows=halo_rows, pressure_groups=pressure_groups, ny=ny, flags=flags)["pressure_groups"]
 
     # -- plumbing ---------------------------------------------------------------
     def _chk(self, rc: int, what: str):

@@ -465,16 +465,19 @@ void enq_diffuse(fluid_ctx *c, int out_m, bool with_div = false) {
 }
 
 // simulateVorticity()  kernel.cu:557-580
-void enq_vorticity(fluid_ctx *c) {
+// out_m: halo margin the forced velocity must cover (slabs; the curl is needed one row beyond it, and
+// reads the diffused velocity one row beyond that)
+void enq_vorticity(fluid_ctx *c, int out_m = 0) {
   const double cells = (double)cells_owned(c);
   {
     ProfScope p(c, K_VORTICITY, 12.0 * cells);
-    launch_vorticity(c->stream, c->g, c->own_r0, c->own_r0 + c->rows, c->vel[c->vin], c->vort);
+    const Range r = widened(c, out_m + 1);
+    launch_vorticity(c->stream, c->g, r.r0, r.r1, c->vel[c->vin], c->vort);
   }
   {
     ProfScope p(c, K_ADD_VORTICITY, 20.0 * cells);
-    launch_add_vorticity(c->stream, c->g, c->own_r0, c->own_r0 + c->rows, c->prm.dt, c->vort,
-                         c->vel[c->vin]);
+    const Range r = widened(c, out_m);
+    launch_add_vorticity(c->stream, c->g, r.r0, r.r1, c->prm.dt, c->vort, c->vel[c->vin]);
   }
 }
 
@@ -663,12 +666,14 @@ void enq_velocity_head(fluid_ctx *c) {
   // margins of the dependency cone (zero-width for whole-domain contexts, see widened())
   const int glen = c->groups > 1 ? c->jg : c->prm.pressure_iters;
   const int m_diff = glen + 1;  // diffused velocity feeds divergence on glen rows
-  enq_advect_velocity(c, m_diff + c->prm.diffusion_iters);
+  const bool vrt = (c->prm.flags & FLUID_FLAG_VORTICITY) != 0;
+  const int m_vrt = vrt ? 2 : 0;  // the confinement force on those rows reads the diffused velocity two rows further
+  enq_advect_velocity(c, m_diff + m_vrt + c->prm.diffusion_iters);
   // (vorticity confinement changes the velocity between the two stages.  Slabs: the pipeline path's fused launch
   // covers widened(glen + 1) and its divergence is good one row inside that — widened(glen), all any pressure
   // launch reads; the tile path keeps the separate form there)
-  enq_diffuse(c, m_diff, (c->tile ? c->tile_div && !c->slab : c->tb_div) && !(c->prm.flags & FLUID_FLAG_VORTICITY));
-  if (c->prm.flags & FLUID_FLAG_VORTICITY) enq_vorticity(c);  // kernel.cu:705
+  enq_diffuse(c, m_diff + m_vrt, (c->tile ? c->tile_div && !c->slab : c->tb_div) && !vrt);
+  if (vrt) enq_vorticity(c, m_diff);  // kernel.cu:705
   enq_pressure_group(c, 0);
 }
 void enq_step(fluid_ctx *c, int parts) {
@@ -843,7 +848,10 @@ int fluid_slab_plan(const fluid_params *p, fluid_slab_info *out) {
   const int jg = (p->pressure_iters + out->pressure_groups - 1) / out->pressure_groups;
   out->pressure_groups = jg > 0 ? (p->pressure_iters + jg - 1) / jg : 1;  // no empty last group
   out->halo_prs = out->pressure_groups > 1 ? jg + 1 : 0;
-  out->halo_vel = jg + 1 + p->diffusion_iters + a;
+  // vorticity confinement (FLUID_FLAG_VORTICITY) sits between diffusion and divergence and reads two rows further:
+  // the force on row r needs the curl of rows r - 1 .. r + 1, the curl of row r the velocity of rows r - 1 .. r + 1
+  const int vrt = (p->flags & FLUID_FLAG_VORTICITY) ? 2 : 0;
+  out->halo_vel = jg + 1 + p->diffusion_iters + a + vrt;
   out->has_lo = p->slab_rank > 0;
   out->has_hi = p->slab_rank < p->slab_count - 1;
   // a halo must come from the adjacent slab alone, and the y-border rules read two rows inward
@@ -901,7 +909,6 @@ static int init_ctx(fluid_ctx **out, const fluid_params *p, int inner_of) {
   fluid_slab_info si;
   int prc = fluid_slab_plan(&prm, &si);
   if (prc) return prc;
-  if (prm.slab_count > 1 && (prm.flags & FLUID_FLAG_VORTICITY)) return FLUID_E_UNSUPPORTED;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return FLUID_E_DEVICE;  // no CPU fallback
   if (prm.device < 0 || prm.device >= ndev) return FLUID_E_INVALID;
@@ -1897,7 +1904,7 @@ static int inner_init(fluid_ctx **out, const fluid_params &prm) {
   const bool multi = prm.n_devices >= 2;  // the slabs on device_ids[] instead of side by side on prm.device
   const int G = multi ? prm.n_devices : prm.inner_slabs;
   if (prm.slab_count > 1 || G > 16) return FLUID_E_UNSUPPORTED;  // no slabs of slabs
-  if (prm.flags & (FLUID_FLAG_VORTICITY | FLUID_FLAG_UNFUSED)) return FLUID_E_UNSUPPORTED;
+  if (prm.flags & FLUID_FLAG_UNFUSED) return FLUID_E_UNSUPPORTED;
   fluid_ctx *P = new (std::nothrow) fluid_ctx();
   if (!P) return FLUID_E_NOMEM;
   P->prm = prm;
@@ -2070,8 +2077,11 @@ static int inner_enqueue(fluid_ctx *P, int nsteps, bool halos_joined = false) {
       if (!(halos_joined && k == 0) && (rc = inner_wait_halos(P, i))) return rc;
       // enq_velocity_head in two pieces, with the event between them
       const int m_diff = s->prm.pressure_iters + 1;
-      enq_advect_velocity(s, m_diff + s->prm.diffusion_iters);
-      enq_diffuse(s, m_diff);
+      const bool vrt = (s->prm.flags & FLUID_FLAG_VORTICITY) != 0;
+      const int m_vrt = vrt ? 2 : 0;
+      enq_advect_velocity(s, m_diff + m_vrt + s->prm.diffusion_iters);
+      enq_diffuse(s, m_diff + m_vrt);
+      if (vrt) enq_vorticity(s, m_diff);  // in place on the buffer the diffusion ended in
       HIPCHK(P, hipEventRecord(s->ev_ready, s->stream));
       enq_pressure_group(s, 0);
       enq_gradient_density_rows(s, true);  // the rows the neighbours wait for; flips to the new buffers

@@ -132,8 +132,8 @@ typedef struct fluid_params {
  * whole-domain context and gives the same bits (fluid_read / fluid_write / fluid_add_source /
  * fluid_diagnostics / fluid_geometry see the whole grid; halo rows move between the slabs by
  * device-side copies inside fluid_step), with these limits: the advection reach of slab contexts
- * applies (halo_rows, FLUID_E_HALO if a backtrace is longer); FLUID_FLAG_VORTICITY and
- * FLUID_FLAG_UNFUSED are refused (FLUID_E_UNSUPPORTED), and so are fluid_step_noalloc,
+ * applies (halo_rows, FLUID_E_HALO if a backtrace is longer); FLUID_FLAG_UNFUSED is
+ * refused (FLUID_E_UNSUPPORTED), and so are fluid_step_noalloc,
  * fluid_profile_steps, the single-stage functions, fluid_step_part, fluid_halo_* and fluid_comm_*
  * on such a context.  The shortest slab must hold a halo (fluid_slab_plan's rule).
  */
@@ -302,7 +302,9 @@ FLUID_API int fluid_profile_steps(fluid_ctx *ctx, int nsteps, fluid_kernel_stat 
  *
  * No counterpart in the reference (single GPU).  The step's dependency cone is
  * covered by ONE exchange before the step: each slab receives
- *   halo_vel  = J + 1 + D + A   rows of velocity (Jg instead of J with pressure groups) and
+ *   halo_vel  = J + 1 + D + A   rows of velocity (Jg instead of J with pressure groups; two more
+ *                               with FLUID_FLAG_VORTICITY: the confinement force on a row reads the
+ *                               curl of the rows either side, and that the velocity one row further) and
  *   halo_dens = A               rows of density
  * from each neighbour (J = pressure_iters, D = diffusion_iters, A = halo_rows,
  * the advection reach in rows, default 8) and recomputes the shrinking cone in

@@ -19,11 +19,12 @@ def main():
     overlap = bool(int(sys.argv[5]))
     groups = int(sys.argv[6]) if len(sys.argv) > 6 else 0
     transport = sys.argv[7] if len(sys.argv) > 7 else "torch"   # "staged": the exchange posted by the library itself
+    flags = int(sys.argv[8]) if len(sys.argv) > 8 else 0        # fluid_params.flags (1: vorticity confinement)
     dist.init_process_group(backend, rank=rank, world_size=world)
     pkg = fluid_amd_loader.load()
     from fluid_simulation_amd.slab import SlabSim
     sim = SlabSim(pkg, n, rank=rank, world=world, device_index=0, pressure_iters=J, halo_rows=2,
-                  overlap=overlap, pressure_groups=groups, transport=transport)
+                  overlap=overlap, pressure_groups=groups, transport=transport, flags=flags)
     ss = pkg.SplatStream()
     for s in range(steps):
         if s % 2 == 0:
@@ -35,7 +36,7 @@ def main():
     sim.step(1)                            # and the halos it consumed are sent again
     fields = {f: sim.gather(f) for f in (pkg.FIELD_VELOCITY, pkg.FIELD_DENSITY, pkg.FIELD_PRESSURE)}
     if rank == 0:
-        whole = pkg.FluidSim(n, pressure_iters=J)
+        whole = pkg.FluidSim(n, pressure_iters=J, flags=flags)
         ss = pkg.SplatStream()
         for s in range(steps):
             if s % 2 == 0:

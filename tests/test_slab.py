@@ -38,6 +38,10 @@ def test_slab_plan_arithmetic(pkg, hip):
     # whole domain
     p = hip.slab_plan(512, 0, 1)
     assert (p["row0"], p["rows"], p["halo_vel"], p["store_rows"]) == (0, 512, 0, 512)
+    # vorticity confinement between diffusion and divergence reads two rows further (include/fluid.h)
+    pv = hip.slab_plan(n, 3, world, diffusion_iters=D, pressure_iters=J, halo_rows=A, flags=pkg.FLAG_VORTICITY)
+    assert pv["halo_vel"] == J + 1 + D + A + 2 and pv["halo_dens"] == A
+    assert pv["store_rows"] == pv["rows"] + 2 * pv["halo_vel"]
     # a slab shorter than its halo cannot be served by the adjacent slab alone
     with pytest.raises(pkg.FluidError):
         hip.slab_plan(256, 0, 8, pressure_iters=40)
@@ -130,6 +134,42 @@ def test_slabs_with_split_tail_equal_whole_domain(pkg, hip, count, n, D, J, A, G
     assert_bit_equal(group.read(pkg.FIELD_DENSITY), whole.read(pkg.FIELD_DENSITY), "density after diagnostics")
     with pytest.raises(pkg.FluidError):
         group.sims[0].step_part(pkg.PART_TAIL_DENSITY_INTERIOR)  # no edges launch pending
+    group.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", ["tiles", "pipeline", "unfused"])
+@pytest.mark.parametrize("count,n,D,J,A,G,split,early", [(2, 256, 10, 10, 1, 0, False, False), (3, 300, 3, 7, 2, 2, True, False),
+                                                         (4, 512, 10, 40, 8, 0, True, True), (2, 128, 1, 1, 1, 0, False, False),
+                                                         (3, 384, 10, 30, 1, 3, False, False)])
+def test_slabs_with_vorticity_confinement_equal_whole_domain(pkg, hip, count, n, D, J, A, G, split, early, path, monkeypatch):
+    """FLUID_FLAG_VORTICITY on slab contexts (kernel.cu:207-263, :557-580, the call at :705): the curl and the
+    confinement force are recomputed in the halo like every other stage, two velocity rows deeper.  A = 1 makes the
+    halo exactly as deep as the dependency cone.  Bit for bit against the whole-domain context with the same flag
+    (itself held to the oracle by test_vorticity_stage_bit_exact), the vorticity field included."""
+    import fluid_simulation_amd.slab as slab
+    flags = pkg.FLAG_VORTICITY | (pkg.FLAG_UNFUSED if path == "unfused" else 0)
+    if path != "unfused":
+        monkeypatch.setenv("FLUID_TILE", "1" if path == "tiles" else "0")
+    if path == "unfused":
+        split = early = False
+    whole = pkg.FluidSim(n, diffusion_iters=D, pressure_iters=J, flags=flags)
+    plain = pkg.FluidSim(n, diffusion_iters=D, pressure_iters=J, flags=flags & ~pkg.FLAG_VORTICITY)
+    group = slab.LocalSlabGroup(pkg, n, count, split_tail=split, early_advect=early, diffusion_iters=D, pressure_iters=J,
+                                halo_rows=A, pressure_groups=G, flags=flags)
+    assert group.sims[1].halo_bytes(-1) == n * ((-(-J // max(G, 1)) + 1 + D + A + 2) * 8 + A * 16)
+    ss = [pkg.SplatStream() for _ in range(3)]
+    for s in range(6):
+        if s % 2 == 0:
+            for sim, st in zip((whole, plain, group), ss):
+                sim.add_source(*st.splat())
+        for sim in (whole, plain, group):
+            sim.step(1)
+    for f, fid in (("velocity", pkg.FIELD_VELOCITY), ("density", pkg.FIELD_DENSITY), ("pressure", pkg.FIELD_PRESSURE),
+                   ("divergence", pkg.FIELD_DIVERGENCE), ("vorticity", pkg.FIELD_VORTICITY)):
+        assert_bit_equal(group.read(fid), whole.read(fid), f"{f} count={count} {path}")
+    # the stage did something: the run with the flag differs from the run without it
+    assert not np.array_equal(whole.read(pkg.FIELD_VELOCITY), plain.read(pkg.FIELD_VELOCITY))
     group.close()
 
 
@@ -345,8 +385,9 @@ def test_slabsim_multiprocess_on_one_gpu(world, overlap):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,n,J,groups", [(2, 512, 10, 0), (4, 512, 10, 0), (3, 384, 30, 3)])
-def test_library_driven_exchange_multiprocess_on_one_gpu(world, n, J, groups):
+@pytest.mark.parametrize("world,n,J,groups,flags", [(2, 512, 10, 0, 0), (4, 512, 10, 0, 0), (3, 384, 30, 3, 0),
+                                                    (3, 384, 10, 0, 1)], ids=["2", "4", "3-groups", "3-vorticity"])
+def test_library_driven_exchange_multiprocess_on_one_gpu(world, n, J, groups, flags):
     """fluid_step on slab contexts with a transport attached (fluid_comm_attach): the library posts
     the exchange itself, straight out of and into the field rows, between the edge and interior
     launches of the last kernel, and runs the interior advection ahead of the halos.  One process
@@ -360,7 +401,7 @@ def test_library_driven_exchange_multiprocess_on_one_gpu(world, n, J, groups):
                    MASTER_PORT=str(port), GLOO_SOCKET_IFNAME="lo")
         procs.append(subprocess.Popen(
             [sys.executable, os.path.join(ROOT, "tests", "slab_gpu_worker.py"), "gloo", str(n), str(J), "6", "1",
-             str(groups), "staged"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+             str(groups), "staged", str(flags)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
     for p in procs:
         try:

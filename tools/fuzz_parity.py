@@ -116,19 +116,20 @@ for i in range(nc):
     count = int(rng.integers(2, 7))
     D, J, A = int(rng.integers(0, 11)), int(rng.integers(0, 41)), int(rng.integers(1, 9))
     G = int(rng.integers(0, 4))
-    need = (J + max(G, 1) - 1) // max(G, 1) + 1 + D + A
+    need = (J + max(G, 1) - 1) // max(G, 1) + 1 + D + A + 2
     n = int(rng.integers(max(count * (need + 4), 64), 2200 if rng.random() < 0.7 else 4400))
     if rng.random() < 0.7:
         n = n // 2 * 2   # odd widths take the straight kernels
     split = bool(rng.random() < 0.6)
     fl = pkg.FLAG_UNFUSED if rng.random() < 0.2 else 0
+    vt = pkg.FLAG_VORTICITY if rng.random() < 0.3 else 0   # the confinement stage, two halo rows deeper
     try:
         grp = slab.LocalSlabGroup(pkg, n, count, split_tail=split and not fl, early_advect=bool(rng.random() < 0.5),
-                                  diffusion_iters=D, pressure_iters=J, halo_rows=A, pressure_groups=G, flags=fl)
+                                  diffusion_iters=D, pressure_iters=J, halo_rows=A, pressure_groups=G, flags=fl | vt)
     except pkg.FluidError as e:
         print("skip", n, count, D, J, A, G, e)
         continue
-    whole = pkg.FluidSim(n, diffusion_iters=D, pressure_iters=J)
+    whole = pkg.FluidSim(n, diffusion_iters=D, pressure_iters=J, flags=vt)
     ss_a, ss_b = pkg.SplatStream(), pkg.SplatStream()
     for s in range(3):
         whole.add_source(*ss_a.splat())
@@ -138,7 +139,7 @@ for i in range(nc):
     for name, fid in F[:3]:
         if not same(grp.read(fid), whole.read(fid)):
             bad += 1
-            print("MISMATCH C", n, count, D, J, A, G, split, name, flush=True)
+            print("MISMATCH C", n, count, D, J, A, G, split, fl, vt, name, flush=True)
             break
     grp.close(); whole.close()
 print(f"C done ({nc} cases), mismatches {bad}", flush=True)
@@ -199,15 +200,16 @@ for i in range(ne):
         os.environ.pop(k, None)
     G = int(rng.integers(2, 6))
     D, J, A = int(rng.integers(0, 13)), int(rng.integers(0, 46)), int(rng.integers(1, 9))
-    need = J + 1 + D + A
+    need = J + 1 + D + A + 2
+    vt = pkg.FLAG_VORTICITY if rng.random() < 0.3 else 0
     n = int(rng.integers(max(G * (need + 4), 32), 1500 if rng.random() < 0.8 else 3000)) // 2 * 2
     ny = int(rng.integers(max(G * (need + 4), 32), 1500)) if rng.random() < 0.3 else 0
     env = {"FLUID_TB_KJ": int(rng.choice([2, 5, 8, 10, 14])), "FLUID_TB_KD": int(rng.choice([2, 5, 10])),
            "FLUID_TB_WAVES": int(rng.choice([7, 64, 500, 2048])), "FLUID_TILE": int(rng.integers(0, 2))} if rng.random() < 0.6 else {}
-    ref = pkg.FluidSim(n, ny=ny, diffusion_iters=D, pressure_iters=J)
+    ref = pkg.FluidSim(n, ny=ny, diffusion_iters=D, pressure_iters=J, flags=vt)
     os.environ.update({k: str(v) for k, v in env.items()})
     try:
-        tst = pkg.FluidSim(n, ny=ny, diffusion_iters=D, pressure_iters=J, halo_rows=A, inner_slabs=G)
+        tst = pkg.FluidSim(n, ny=ny, diffusion_iters=D, pressure_iters=J, halo_rows=A, inner_slabs=G, flags=vt)
     except pkg.FluidError as e:
         print("skip", n, ny, G, D, J, A, env, e)
         ref.close()
@@ -232,7 +234,7 @@ for i in range(ne):
             if not same(tst.read(fid), ref.read(fid)):
                 bad += 1
                 ok = False
-                print("MISMATCH E", n, ny, G, D, J, A, env, name, "call", s_, flush=True)
+                print("MISMATCH E", n, ny, G, D, J, A, env, vt, name, "call", s_, flush=True)
                 break
         if not ok:
             break
