@@ -70,6 +70,16 @@ constexpr int RING = TB_RING;
 #ifndef TB_DIV_STEADY
 #define TB_DIV_STEADY 1  // its steady-state loop (20 VGPRs)
 #endif
+// The pipelines store their output rows through a buffer resource (end of round 3): the lanes and rows that must
+// not be stored (x halo of a strip, y halo of a chunk) get an offset beyond the resource and the hardware drops
+// them — still an unconditional instruction, so the counted waits stay — instead of writing a dump row (28 % of
+// a 16384^2 pressure launch's store requests, 43 % at 4096^2, all of them L2 traffic).  16384^2: k_jacobi_tb
+// 754 -> 738 us, k_jacobi0_tb 689 -> 673, k_diffuse_div_tb 1231 -> 1186, the step 6.51 -> 6.45 ms; 4096^2: 67.6 ->
+// 65.2, 70.1 -> 69.0, 98.1 -> 93.6.  Non-temporal on top (TB_BUFST_AUX=2): slower again (766 / 679 / 1209 us).
+// 0: pointers and the dump row, as before (the divergence rows of k_jacobi_div_tb still go that way).
+#ifndef TB_BUFST
+#define TB_BUFST 1
+#endif
 #ifndef TB_CHAIN_MINK
 #define TB_CHAIN_MINK 10  // chained chunks (Pipe::run) are instantiated from this sweep count up
 #endif
@@ -191,6 +201,50 @@ __device__ __forceinline__ void store_row2(float2 *p, const Row2<C> &r) {
     reinterpret_cast<float4 *>(p)[c / 2] = make_float4(r.u[c], r.w[c], r.u[c + 1], r.w[c + 1]);
 }
 
+// Stores through a raw buffer resource (TB_BUFST): an offset at or beyond num_records is dropped by the hardware,
+// which is how the lanes and rows that must not be stored are kept out of memory without a branch, an EXEC mask
+// or a dump row.  kOobOffset is beyond any resource made here (tb_rsrc: at most 0xFFFFFF00 bytes), and so are the
+// up to 32 bytes a lane stores from it (no wrap-around to offset 0).
+constexpr unsigned kOobOffset = 0xFFFFFF80u;
+#ifndef TB_BUFST_AUX
+#define TB_BUFST_AUX 0  // cache policy bits of the stores (2: non-temporal)
+#endif
+template <int C>
+__device__ __forceinline__ void buf_store_row(__amdgpu_buffer_rsrc_t rs, unsigned boff, const Row<C> &r) {
+  if constexpr (C == 4) {
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    v4i d; d.x = __float_as_int(r.v[0]); d.y = __float_as_int(r.v[1]); d.z = __float_as_int(r.v[2]); d.w = __float_as_int(r.v[3]);
+    __builtin_amdgcn_raw_buffer_store_b128(d, rs, (int)boff, 0, TB_BUFST_AUX);
+  } else if constexpr (C == 2) {
+    typedef int v2i __attribute__((ext_vector_type(2)));
+    v2i d; d.x = __float_as_int(r.v[0]); d.y = __float_as_int(r.v[1]);
+    __builtin_amdgcn_raw_buffer_store_b64(d, rs, (int)boff, 0, TB_BUFST_AUX);
+  } else {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(r.v[0]), rs, (int)boff, 0, TB_BUFST_AUX);
+  }
+}
+template <int C>
+__device__ __forceinline__ void buf_store_row2(__amdgpu_buffer_rsrc_t rs, unsigned boff, const Row2<C> &r) {
+  typedef int v4i __attribute__((ext_vector_type(4)));
+  static_assert(C == 2 || C == 4, "two or four columns per lane");
+  const v4i d0 = {__float_as_int(r.u[0]), __float_as_int(r.w[0]), __float_as_int(r.u[1]), __float_as_int(r.w[1])};
+  __builtin_amdgcn_raw_buffer_store_b128(d0, rs, (int)boff, 0, TB_BUFST_AUX);
+  if constexpr (C == 4) {
+    const v4i d1 = {__float_as_int(r.u[2]), __float_as_int(r.w[2]), __float_as_int(r.u[3]), __float_as_int(r.w[3])};
+    __builtin_amdgcn_raw_buffer_store_b128(d1, rs, (int)(boff + 16u), 0, TB_BUFST_AUX);
+  }
+}
+// where a row of the stage after the last level goes (DiffuseDivOp::Tail::push): a pointer, or a buffer offset
+template <int C> struct PtrDst {
+  float *q;
+  __device__ __forceinline__ void put(const Row<C> &d) const { store_row<C>(q, d); }
+};
+template <int C> struct BufDst {
+  __amdgpu_buffer_rsrc_t rs;
+  unsigned boff;
+  __device__ __forceinline__ void put(const Row<C> &d) const { buf_store_row<C>(rs, boff, d); }
+};
+
 // Rows handed from one chunk to the chunk above it (chained chunks, see Pipe::run): 8-byte words,
 // word w of a lane at q[w * WAVE].  The two chunks run on any two CUs, possibly of two XCDs whose
 // L2s do not snoop each other, so both sides use agent-scope atomics: the store is written through
@@ -267,6 +321,7 @@ __device__ __forceinline__ void diffuse_row2_asm(float &o0, float &o1, float b0,
 
 // pressureJacobi, kernel.cu:291-324
 template <int C> struct JacobiOp {
+  static constexpr int kCols = C;
   using R = Row<C>;
   using A = Row<C>;  // divergence row
   using Elem = float;
@@ -279,6 +334,10 @@ template <int C> struct JacobiOp {
     return real ? p.out + off : p.dump + doff;
   }
   static __device__ __forceinline__ void store_at(Elem *q, const R &r) { store_row<C>(q, r); }
+  static constexpr bool kBufStore = TB_BUFST != 0;
+  static __device__ __forceinline__ void store_buf(__amdgpu_buffer_rsrc_t rs, unsigned boff, const R &r) {
+    buf_store_row<C>(rs, boff, r);
+  }
   static constexpr bool kLoadsField = true;   // level 0 is read from memory
   static constexpr bool kStoresAux = false;   // the auxiliary rows are only read
   static constexpr int kTailRows = 0;  // no stage after the last level (DiffuseDivOp has one)
@@ -368,6 +427,7 @@ template <int C> struct JacobiOp {
 
 // diffusion, kernel.cu:173-205 (float2 field: two planes per column)
 template <int C> struct DiffuseOp {
+  static constexpr int kCols = C;
   using R = Row2<C>;
   using A = NoAux;
   using Elem = float2;
@@ -380,6 +440,13 @@ template <int C> struct DiffuseOp {
     return real ? p.out + off : p.dump + doff;
   }
   static __device__ __forceinline__ void store_at(Elem *q, const R &r) { store_row2<C>(q, r); }
+  // (two columns per lane only: the compiler assembles the second 16 bytes of a four-column row through scratch
+  // memory — scratch_store 24 bytes, scratch_load 16 at offset 8 — whichever way the vector is written down; the
+  // four-column plans are not a default anywhere and keep the pointer stores)
+  static constexpr bool kBufStore = TB_BUFST != 0 && C == 2;
+  static __device__ __forceinline__ void store_buf(__amdgpu_buffer_rsrc_t rs, unsigned boff, const R &r) {
+    buf_store_row2<C>(rs, boff, r);
+  }
   static constexpr bool kLoadsField = true;
   static constexpr bool kStoresAux = false;
   static constexpr bool kSteady = true;  // two planes per column: issue-bound, 1.14 -> 1.06 ms at 16384^2
@@ -478,8 +545,8 @@ template <int C> struct DiffuseDivOp : DiffuseOp<C> {
       for (int c = 0; c < C; ++c) w2[c] = 0.0f;
     }
     // fin = final row r; stores the divergence of row r - 1 at dst (its real place or the dump row)
-    template <bool XEDGE, bool YCHK>
-    __device__ __forceinline__ void push(const R &fin, int r, int x0, int N, int NY, float *dst) {
+    template <bool XEDGE, bool YCHK, class Dst>
+    __device__ __forceinline__ void push(const R &fin, int r, int x0, int N, int NY, Dst dst) {
       Row<C> d;
       if (YCHK && (r - 1 <= 0 || r - 1 >= NY - 1)) {  // wave-uniform: border rows, kernel.cu:287
         d = zero_row<C>();
@@ -498,7 +565,7 @@ template <int C> struct DiffuseDivOp : DiffuseOp<C> {
           d.v[c] = v;
         }
       }
-      store_row<C>(dst, d);
+      dst.put(d);
 #pragma unroll
       for (int c = 0; c < C; ++c) w2[c] = f1.w[c];
       f1 = fin;
@@ -665,6 +732,9 @@ template <class Op, int K, bool XEDGE, bool CHAIN = false> struct Pipe {
   static_assert(!(CHAIN && T > 0), "no chained form of the launch with a stage after the last level");
   typename Op::Tail tail;
   bool st_ok;
+  // Op::kBufStore: rows [st_a, st_b) of the output field (and of the field the stage after the last level writes)
+  // as buffer resources; a stored row's offset is relative to row st_a
+  __amdgpu_buffer_rsrc_t obuf, dbuf;
   XBorder xb;  // meaningful in x-border strips only
   // chained chunks (CHAIN): this wave's record of side rows and the record of the chunk below it
   // (same strip), as per-lane pointers; the flags that say a record is complete; which ends of
@@ -696,6 +766,19 @@ template <class Op, int K, bool XEDGE, bool CHAIN = false> struct Pipe {
     return (size_t)r * g.n + xc;
   }
 
+  // store row `ro` of the output field (element offset o) if `real`, else nowhere (or into the dump row)
+  __device__ __forceinline__ void put(const P &p, bool real, int ro, const R &fin) {
+    if constexpr (Op::kBufStore) {
+      Op::store_buf(obuf, real ? boff(ro, sizeof(Elem)) : kOobOffset, fin);
+    } else {
+      Op::store_at(Op::out_ptr(p, real, off(ro), (size_t)xc), fin);
+    }
+  }
+  // byte offset of this lane's columns of row r (st_a <= r < st_b) from the start of row st_a
+  __device__ __forceinline__ unsigned boff(int r, size_t elem) const {
+    return ((unsigned)(r - st_a) * (unsigned)g.n + (unsigned)xc) * (unsigned)elem;
+  }
+
   __device__ __forceinline__ void init(const P &p, int t0) {
 #pragma unroll
     for (int l = 0; l < K; ++l) {
@@ -718,11 +801,15 @@ template <class Op, int K, bool XEDGE, bool CHAIN = false> struct Pipe {
   }
   // the stage after the last level: fin is final row ro; its output is row ro - 1
   template <bool YCHK>
-  __device__ __forceinline__ void tail_push(const P &p, const R &fin, int ro, float *dst) {
-    tail.template push<XEDGE, YCHK>(fin, ro, x0, g.n, g.ny, dst);
-  }
-  __device__ __forceinline__ float *tail_dst(const P &p, int rd) const {
-    return st_ok && rd >= st_a && rd < st_b ? p.div_out + off(rd) : (float *)p.dump + 2 * (size_t)g.n + xc;
+  __device__ __forceinline__ void tail_push(const P &p, const R &fin, int ro) {
+    const int rd = ro - 1;
+    const bool real = st_ok && rd >= st_a && rd < st_b;
+    if constexpr (Op::kBufStore) {
+      tail.template push<XEDGE, YCHK>(fin, ro, x0, g.n, g.ny, BufDst<Op::kCols>{dbuf, real ? boff(rd, sizeof(float)) : kOobOffset});
+    } else {
+      tail.template push<XEDGE, YCHK>(fin, ro, x0, g.n, g.ny,
+                                      PtrDst<Op::kCols>{real ? p.div_out + off(rd) : (float *)p.dump + 2 * (size_t)g.n + xc});
+    }
   }
 
   __device__ __forceinline__ void shift_aux() {
@@ -764,10 +851,10 @@ template <class Op, int K, bool XEDGE, bool CHAIN = false> struct Pipe {
     if (t - K >= 1 && t - 1 <= g.ny - 2) fin = levels<J, false>(p, t, cur);  // every level's row is y-interior
     else fin = levels<J, true>(p, t, cur);
     const int ro = t - K;  // level K row just produced
-    Op::store_at(Op::out_ptr(p, st_ok && ro >= st_a && ro < st_b, off(ro), (size_t)xc), fin);
+    put(p, st_ok && ro >= st_a && ro < st_b, ro, fin);
     if constexpr (T > 0) {
-      if (ro - 1 >= 1 && ro - 1 <= g.ny - 2) tail_push<false>(p, fin, ro, tail_dst(p, ro - 1));
-      else tail_push<true>(p, fin, ro, tail_dst(p, ro - 1));
+      if (ro - 1 >= 1 && ro - 1 <= g.ny - 2) tail_push<false>(p, fin, ro);
+      else tail_push<true>(p, fin, ro);
     }
   }
 
@@ -799,8 +886,8 @@ template <class Op, int K, bool XEDGE, bool CHAIN = false> struct Pipe {
       const R fin = levels<J, YCHK, LV>(p, t, cur);
       if constexpr (LV == K) {
         const int ro = t - K;
-        Op::store_at(Op::out_ptr(p, st_ok && ro >= st_a && ro < st_b, off(ro), (size_t)xc), fin);
-        if constexpr (T > 0) tail_push<YCHK>(p, fin, ro, tail_dst(p, ro - 1));
+        put(p, st_ok && ro >= st_a && ro < st_b, ro, fin);
+        if constexpr (T > 0) tail_push<YCHK>(p, fin, ro);
       }
     }
     // chained chunks: level L = JJ / 2 has just produced the first (JJ even) or second (JJ odd) row
@@ -877,7 +964,7 @@ template <class Op, int K, bool XEDGE, bool CHAIN = false> struct Pipe {
     // every row computed here is y-interior and one this chunk stores (the host only chains
     // chunks of at least RAMP + 2 * RING rows, tb_chain_chunk_ok)
     const R fin = levels<J, false, K, LO>(p, t, cur);
-    Op::store_at(Op::out_ptr(p, st_ok, off(t - K), (size_t)xc), fin);
+    put(p, st_ok, t - K, fin);
   }
   template <int EE>
   __device__ __forceinline__ void down(const P &p, int td) {
@@ -896,11 +983,16 @@ template <class Op, int K, bool XEDGE, bool CHAIN = false> struct Pipe {
     Elem *sp;        // where this lane stores row t-K
     float *dp;       // where it stores auxiliary row t (kStoresAux)
     size_t sstride;  // n for storing lanes, 0 for dump lanes
+    unsigned so, sinc, dpo, dinc;  // Op::kBufStore: the same as byte offsets into obuf / dbuf (dropped lanes stay out of range)
   };
   __device__ __forceinline__ void steady_init(const P &p, int t, Steady &st) const {
     st.ro = (size_t)(t - g.ybase) * g.n;
     st.sstride = st_ok ? (size_t)g.n : 0;
     st.sp = Op::out_ptr(p, st_ok, (size_t)(t - K - g.ybase) * g.n + xc, (size_t)xc);
+    st.so = st_ok ? boff(t - K, sizeof(Elem)) : kOobOffset;
+    st.sinc = st_ok ? (unsigned)g.n * (unsigned)sizeof(Elem) : 0u;
+    st.dpo = st_ok ? boff(t - K - 1, sizeof(float)) : kOobOffset;
+    st.dinc = st_ok ? (unsigned)g.n * (unsigned)sizeof(float) : 0u;
     st.dp = nullptr;
     if constexpr (Op::kStoresAux) st.dp = st_ok ? p.div_out + st.ro + xc : p.dump + (size_t)g.n + xc;
     if constexpr (T > 0)  // divergence row t - K - 1
@@ -918,10 +1010,20 @@ template <class Op, int K, bool XEDGE, bool CHAIN = false> struct Pipe {
     if constexpr (Op::kStoresAux)
       feed.template produce<J, false>(*this, p, t, st.ro + (RING + 1) * n + (unsigned)xc, st.dp);
     const R fin = levels<J, false>(p, t, cur);
-    Op::store_at(st.sp, fin);
-    if constexpr (T > 0) tail_push<false>(p, fin, t - K, st.dp);
-    st.sp += st.sstride;
-    if constexpr (Op::kStoresAux || T > 0) st.dp += st.sstride;
+    if constexpr (Op::kBufStore) {
+      Op::store_buf(obuf, st.so, fin);
+      if constexpr (T > 0) {
+        tail.template push<XEDGE, false>(fin, t - K, x0, g.n, g.ny, BufDst<Op::kCols>{dbuf, st.dpo});
+        st.dpo += st.dinc;
+      }
+      st.so += st.sinc;
+      if constexpr (Op::kStoresAux) st.dp += st.sstride;
+    } else {
+      Op::store_at(st.sp, fin);
+      if constexpr (T > 0) tail.template push<XEDGE, false>(fin, t - K, x0, g.n, g.ny, PtrDst<Op::kCols>{st.dp});
+      st.sp += st.sstride;
+      if constexpr (Op::kStoresAux || T > 0) st.dp += st.sstride;
+    }
     st.ro += n;
   }
 
@@ -1036,6 +1138,24 @@ __device__ __forceinline__ void chain_setup(PipeT &pipe, TbChain ch, int nstr, i
   pipe.takes_from_below = chunk_below;
 }
 
+// The stored rows of a field as a raw buffer resource (stride 0, 32-bit data format: dword 3 as gfx942 / gfx950
+// want it); the context refuses fields of 4 GiB and more on this path (fluid_api.hip).
+// (the host keeps a chunk's rows under 0xFFFFFF00 bytes: tb_chunk_fits_buffer)
+template <class T>
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tb_rsrc(T *field, Geom g, int ya, int yb) {
+  T *base = field + (size_t)(ya - g.ybase) * g.n;
+  const size_t bytes = (size_t)(yb - ya) * g.n * sizeof(T);
+  return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)(unsigned)bytes, 0x00020000);
+}
+template <class Op, class PipeT>
+__device__ __forceinline__ void tb_set_buffers(PipeT &pipe, const typename Op::P &p, Geom g, int ya, int yb) {
+  if constexpr (Op::kBufStore) {
+    pipe.obuf = tb_rsrc(p.out, g, ya, yb);
+    if constexpr (Op::kTailRows > 0) pipe.dbuf = tb_rsrc(p.div_out, g, ya, yb);
+    else pipe.dbuf = pipe.obuf;
+  }
+}
+
 template <class Op, int K, int C, bool CHAIN = false>
 __device__ __forceinline__ void tb_kernel_body(Geom g, int r0, int r1, int chunk,
                                                const typename Op::P &p, TbChain ch = TbChain{}) {
@@ -1086,6 +1206,7 @@ __device__ __forceinline__ void tb_kernel_body(Geom g, int r0, int r1, int chunk
     pipe.trace = ch.trace ? ch.trace + (size_t)(by * gx * WAVES_PER_BLOCK + strip) * 4 : nullptr;
     pipe.sync = ch.sync != 0;
     pipe.xb = x_border(x0, g.n);
+    tb_set_buffers<Op>(pipe, p, g, ya, yb);
     if constexpr (CHAIN) chain_setup(pipe, ch, gx * WAVES_PER_BLOCK, by, strip, lane, yb < g.ybase + r1);
     pipe.run(p);
   } else {
@@ -1095,6 +1216,7 @@ __device__ __forceinline__ void tb_kernel_body(Geom g, int r0, int r1, int chunk
     pipe.trace = ch.trace ? ch.trace + (size_t)(by * gx * WAVES_PER_BLOCK + strip) * 4 : nullptr;
     pipe.sync = ch.sync != 0;
     pipe.xb = XBorder{0, 0};
+    tb_set_buffers<Op>(pipe, p, g, ya, yb);
     if constexpr (CHAIN) chain_setup(pipe, ch, gx * WAVES_PER_BLOCK, by, strip, lane, yb < g.ybase + r1);
     pipe.run(p);
   }
@@ -1141,6 +1263,12 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK) void k_jacobi0_tb(
     float *__restrict__ dump, TbChain ch) {
   typename JacobiZeroOp<C>::P p{nullptr, div, pout, dump};
   tb_kernel_body<JacobiZeroOp<C>, K, C, false>(g, r0, r1, chunk, p, ch);
+}
+
+// A chunk's stored rows are addressed through a buffer resource with 32-bit offsets (TB_BUFST): refused beyond
+// that (a launch plan of very few chunk-rows on a grid of tens of thousands of columns; never a default plan).
+inline bool tb_chunk_fits_buffer(Geom g, int chunk, size_t elem) {
+  return !TB_BUFST || (unsigned long long)chunk * (unsigned long long)g.n * elem <= 0xFFFFFF00ull;
 }
 
 template <int K, int C>
@@ -1298,7 +1426,7 @@ size_t tb_chain_flags(int n, int k, int cols, int chunks) {
 bool launch_jacobi_tb(hipStream_t s, Geom g, int r0, int r1, int k, int cols, int chunk,
                       const float *pin, const float *div, float *pout, void *dump, const TbChain *chained) {
   if (r1 <= r0) return true;
-  if (!tb_supported(g.n, cols) || chunk < 1 || !tb_has_k(k, cols, false)) return false;
+  if (!tb_supported(g.n, cols) || chunk < 1 || !tb_has_k(k, cols, false) || !tb_chunk_fits_buffer(g, chunk, sizeof(float))) return false;
   TbChain plain{};  // not chainable: only the trace pointer goes along
   if (chained && (!chained->side || !tb_chain_chunk_ok(k, cols, chunk, r1 - r0))) { plain.trace = chained->trace; plain.sync = chained->sync; chained = &plain; }
   if (cols == 4) TB_DISPATCH_K4(jacobi_tb_launch, s, g, r0, r1, chunk, pin, div, pout, dump, chained)
@@ -1312,7 +1440,7 @@ bool launch_jacobi_tb(hipStream_t s, Geom g, int r0, int r1, int k, int cols, in
 bool launch_jacobi_div_tb(hipStream_t s, Geom g, int r0, int r1, int k, int cols, int chunk,
                           const float2 *vel, float *div_out, float *pout, void *dump, const TbChain *chained) {
   if (r1 <= r0) return true;
-  if (!tb_supported(g.n, cols) || chunk < 1 || !tb_has_k(k, cols, false)) return false;
+  if (!tb_supported(g.n, cols) || chunk < 1 || !tb_has_k(k, cols, false) || !tb_chunk_fits_buffer(g, chunk, sizeof(float))) return false;
   TbChain plain{};  // not chainable: only the trace pointer goes along
   if (chained && (!chained->side || !tb_chain_chunk_ok(k, cols, chunk, r1 - r0))) { plain.trace = chained->trace; plain.sync = chained->sync; chained = &plain; }
   if (cols == 4) TB_DISPATCH_K4(jacobi_div_tb_launch, s, g, r0, r1, chunk, vel, div_out, pout, dump, chained)
@@ -1326,7 +1454,7 @@ bool launch_jacobi_div_tb(hipStream_t s, Geom g, int r0, int r1, int k, int cols
 bool launch_diffuse_tb(hipStream_t s, Geom g, int r0, int r1, int k, int cols, int chunk,
                        float alpha, float beta, const float2 *vin, float2 *vout, void *dump, const TbChain *chained) {
   if (r1 <= r0) return true;
-  if (!tb_supported(g.n, cols) || chunk < 1 || !tb_has_k(k, cols, true)) return false;
+  if (!tb_supported(g.n, cols) || chunk < 1 || !tb_has_k(k, cols, true) || !tb_chunk_fits_buffer(g, chunk, sizeof(float2))) return false;
   TbChain plain{};  // not chainable: only the trace pointer goes along
   if (chained && (!chained->side || !tb_chain_chunk_ok(k, cols, chunk, r1 - r0))) { plain.trace = chained->trace; plain.sync = chained->sync; chained = &plain; }
   if (cols == 4) TB_DISPATCH_K4(diffuse_tb_launch, s, g, r0, r1, chunk, alpha, beta, vin, vout, dump, chained)
@@ -1340,7 +1468,7 @@ bool tb_has_div_k(int k, int cols) { return cols == 2 && (k == 8 || k == 10); }
 bool launch_diffuse_div_tb(hipStream_t s, Geom g, int r0, int r1, int k, int cols, int chunk, float alpha, float beta,
                            const float2 *vin, float2 *vout, float *div_out, void *dump, const TbChain *extra) {
   if (r1 <= r0) return true;
-  if (!tb_supported(g.n, cols) || chunk < 1 || !tb_has_div_k(k, cols)) return false;
+  if (!tb_supported(g.n, cols) || chunk < 1 || !tb_has_div_k(k, cols) || !tb_chunk_fits_buffer(g, chunk, sizeof(float2))) return false;
   TbChain plain{};  // never chained: the trace pointer and the barrier flag go along
   if (extra) { plain.trace = extra->trace; plain.sync = extra->sync; }
   if (k == 8) diffuse_div_tb_launch<8, 2>(s, g, r0, r1, chunk, alpha, beta, vin, vout, div_out, dump, &plain);
@@ -1363,7 +1491,7 @@ bool tb_occ_part2(int kind, int k, int cols, int *out) {
 bool launch_jacobi0_tb(hipStream_t s, Geom g, int r0, int r1, int k, int cols, int chunk, const float *div,
                        float *pout, void *dump, const TbChain *extra) {
   if (r1 <= r0) return true;
-  if (!tb_supported(g.n, cols) || chunk < 1 || !tb_has_k(k, cols, false)) return false;
+  if (!tb_supported(g.n, cols) || chunk < 1 || !tb_has_k(k, cols, false) || !tb_chunk_fits_buffer(g, chunk, sizeof(float))) return false;
   TbChain plain{};
   if (extra) { plain.trace = extra->trace; plain.sync = extra->sync; }
   extra = &plain;

@@ -44,6 +44,12 @@ def test_noalloc_step_equals_step_twice_second_smaller(pkg, hip, monkeypatch):
     # 600^2 with FLUID_TILE=0 forces it on a grid whose strips leave the domain on the right
     twin_run(pkg, hip, 2048, 40, 2)
     twin_run(pkg, hip, 1280, 14, 2)
+    # the plan whose divergence + pressure launch still writes the scratch row (end of round 3: the default plan's
+    # launches drop what they used to sink, see test_noalloc_step_hands_the_kernels_the_static_scratch)
+    monkeypatch.setenv("FLUID_TB_DIV", "0")
+    twin_run(pkg, hip, 2048, 40, 2)
+    twin_run(pkg, hip, 1280, 14, 2)
+    monkeypatch.delenv("FLUID_TB_DIV")
     monkeypatch.setenv("FLUID_TILE", "0")
     twin_run(pkg, hip, 600, 10, 2)
     monkeypatch.delenv("FLUID_TILE")
@@ -87,22 +93,37 @@ def test_noalloc_step_hands_the_kernels_the_static_scratch(pkg, hip, monkeypatch
     fluid_debug_sink can: canary both rows, step, and see which one was written.  fluid_step_noalloc
     must leave the context's own hipMalloc'ed row untouched and write the GPU's static scratch;
     fluid_step the other way round.  600^2 with the pipeline forced: strips leave the domain on the
-    right, so sink columns are certainly written."""
+    right, so sink columns are certainly written.
+
+    End of round 3: the pipelines store their output rows through a buffer resource and drop the lanes and rows
+    they used to sink (fluid_kernels_tb.hip, TB_BUFST); the sink is still what the divergence + pressure launch
+    writes the divergence rows it must not store to, i.e. on plans where the last diffusion launch does not write
+    the divergence itself (FLUID_TB_DIV=0 here; vorticity confinement, odd diffusion counts).  On the default plan
+    neither entry point writes either row any more, which is checked too."""
     monkeypatch.setenv("FLUID_TILE", "0")
-    for n, J in ((600, 10), (2048, 16)):
-        sim = pkg.FluidSim(n, lib=hip, pressure_iters=J)
-        sim.add_source(0.5, 0.5, 10.0, -5.0)
-        for which in (0, 1):
-            sim.debug_sink(which, fill=True)
-            assert sim.debug_sink(which, fill=False) == 0
-        sim.step_noalloc(2)
-        assert sim.debug_sink(0, fill=False) == 0, "fluid_step_noalloc wrote the context's own sink row"
-        assert sim.debug_sink(1, fill=False) > 0, "fluid_step_noalloc did not write the static scratch"
-        sim.debug_sink(1, fill=True)
-        sim.step(2)
-        assert sim.debug_sink(1, fill=False) == 0, "fluid_step wrote the static scratch"
-        assert sim.debug_sink(0, fill=False) > 0, "fluid_step did not write the context's own sink row"
-        sim.close()
+    for tb_div in ("0", None):
+        if tb_div is None:
+            monkeypatch.delenv("FLUID_TB_DIV", raising=False)
+        else:
+            monkeypatch.setenv("FLUID_TB_DIV", tb_div)
+        for n, J in ((600, 10), (2048, 16)):
+            sim = pkg.FluidSim(n, lib=hip, pressure_iters=J)
+            sim.add_source(0.5, 0.5, 10.0, -5.0)
+            for which in (0, 1):
+                sim.debug_sink(which, fill=True)
+                assert sim.debug_sink(which, fill=False) == 0
+            sim.step_noalloc(2)
+            assert sim.debug_sink(0, fill=False) == 0, "fluid_step_noalloc wrote the context's own sink row"
+            if tb_div == "0":
+                assert sim.debug_sink(1, fill=False) > 0, "fluid_step_noalloc did not write the static scratch"
+            sim.debug_sink(1, fill=True)
+            sim.step(2)
+            assert sim.debug_sink(1, fill=False) == 0, "fluid_step wrote the static scratch"
+            if tb_div == "0":
+                assert sim.debug_sink(0, fill=False) > 0, "fluid_step did not write the context's own sink row"
+            else:
+                assert sim.debug_sink(0, fill=False) == 0, "the default plan's launches still sink rows"
+            sim.close()
 
 
 FRESH = r"""
