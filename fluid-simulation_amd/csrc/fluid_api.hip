@@ -353,6 +353,10 @@ int tb_chunk(const fluid_ctx *c, int kind, int k, int cols, int rows) {
   const int chunks = tb_chunk_count(c, kind, k, cols);
   int chunk = (rows + chunks - 1) / chunks;
   if (chunk < c->tb_minchunk * k) chunk = c->tb_minchunk * k;  // bound the y-halo recompute (2k rows per chunk)
+  // a chunk's stored rows are one buffer resource with 32-bit offsets (fluid_kernels_tb.hip, tb_chunk_fits_buffer;
+  // 8 bytes per cell at most): only a plan of a handful of chunk-rows on a grid of tens of thousands of columns gets here
+  const long long fit = 0xFFFFFF00ll / ((long long)c->g.n * 8);
+  if (chunk > fit && fit >= 1) chunk = (int)fit;
   if (c->tb_chain && ((c->tb_chain_kinds >> kind) & 1) && tb_has_k(k, cols, kind == 2) && cols == 2) {
     // chained chunks: a multiple of the pipeline's slot period, long enough for fill and tail; a
     // launch whose rows then fit one chunk (or whose k has no unrolled fill) runs unchained

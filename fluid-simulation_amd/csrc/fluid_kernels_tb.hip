@@ -766,7 +766,7 @@ template <class Op, int K, bool XEDGE, bool CHAIN = false> struct Pipe {
     return (size_t)r * g.n + xc;
   }
 
-  // store row `ro` of the output field (element offset o) if `real`, else nowhere (or into the dump row)
+  // store row `ro` of the output field if `real`; else nowhere (buffer stores) or into the dump row
   __device__ __forceinline__ void put(const P &p, bool real, int ro, const R &fin) {
     if constexpr (Op::kBufStore) {
       Op::store_buf(obuf, real ? boff(ro, sizeof(Elem)) : kOobOffset, fin);
@@ -1138,9 +1138,9 @@ __device__ __forceinline__ void chain_setup(PipeT &pipe, TbChain ch, int nstr, i
   pipe.takes_from_below = chunk_below;
 }
 
-// The stored rows of a field as a raw buffer resource (stride 0, 32-bit data format: dword 3 as gfx942 / gfx950
-// want it); the context refuses fields of 4 GiB and more on this path (fluid_api.hip).
-// (the host keeps a chunk's rows under 0xFFFFFF00 bytes: tb_chunk_fits_buffer)
+// The rows [ya, yb) a chunk stores of a field, as a raw buffer resource (stride 0, 32-bit data format: dword 3 as
+// gfx942 / gfx950 want it).  The host keeps a chunk's rows under 0xFFFFFF00 bytes (tb_chunk in fluid_api.hip
+// shortens the chunk, tb_chunk_fits_buffer refuses what is still longer).
 template <class T>
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t tb_rsrc(T *field, Geom g, int ya, int yb) {
   T *base = field + (size_t)(ya - g.ybase) * g.n;

@@ -226,6 +226,28 @@ def test_large_grid_fused_equals_unfused(pkg, hip, J):
         assert_bit_equal(a, b, f"8192^2 {f}")
 
 
+def test_wide_grid_with_one_chunk_row_fits_the_buffer_offsets(pkg, hip, monkeypatch):
+    """The pipelines store a chunk's rows through a buffer resource with 32-bit offsets (fluid_kernels_tb.hip,
+    TB_BUFST).  65536 columns x 8448 rows with a plan of one chunk-row would make a chunk of 4.4 GB of velocity:
+    tb_chunk must shorten it (and tb_chunk_fits_buffer would refuse it otherwise — a refused launch is an error
+    from fluid_step, not a wrong result).  Fused == straight path, by device-side checksums of every field
+    (34 GB per context: nothing is read back)."""
+    n, ny = 65536, 8448
+    monkeypatch.setenv("FLUID_TB_WAVES", "600")   # fewer waves than strips: one chunk-row
+    sums = []
+    for flags in (0, pkg.FLAG_UNFUSED):
+        s = pkg.FluidSim(n, ny=ny, lib=hip, pressure_iters=14, flags=flags)
+        s.add_source(0.5, 0.5, 400.0, -300.0, (1.0, 0.5, 0.25, 0.0))
+        s.add_source(0.1, 0.95, -300.0, 200.0, (0.0, 0.5, 1.0, 0.0))
+        s.step(2)
+        s.sync()
+        sums.append([s.checksum(f) for f in (pkg.FIELD_VELOCITY, pkg.FIELD_DENSITY, pkg.FIELD_PRESSURE, pkg.FIELD_DIVERGENCE)])
+        d = s.diagnostics()
+        assert d["max_abs_p"] > 0 and d["max_abs_u"] > 0
+        s.close()
+    assert sums[0] == sums[1], sums
+
+
 def test_config0_100_steps_seeded(pkg, hip, oracle):
     """BASELINE.json configs[0] verbatim: the reference's default grid (512^2, D = J = 10), seeded
     splats before step 0 and every 10th step, 100 steps, HIP against the serial host-C
