@@ -184,7 +184,10 @@ FLUID_API int fluid_prepare_steps(fluid_ctx *ctx, int nsteps);
  * bytes (256.25 KiB, one copy per GPU, held until the process ends) instead of the context's own.
  * Calls no hipMalloc / hipFree / allocating routine.  n > FLUID_NOALLOC_MAX_N: FLUID_E_SIZE; slab
  * contexts: FLUID_E_UNSUPPORTED.  Every call on a GPU shares that GPU's array: its contents are
- * never read, so nothing is cleared between calls and calls of different contexts may overlap. */
+ * never read, so nothing is cleared between calls and calls of different contexts may overlap.
+ * (Since the end of round 3 most launches drop those rows in hardware instead; the sink is still
+ * written by the divergence + pressure launch of plans whose last diffusion launch does not write
+ * the divergence itself: FLUID_FLAG_VORTICITY, diffusion counts not ending in 8 or 10 sweeps.) */
 #define FLUID_NOALLOC_MAX_N 16384
 FLUID_API int fluid_step_noalloc(fluid_ctx *ctx, int nsteps);
 
