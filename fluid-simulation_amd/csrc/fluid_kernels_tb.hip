@@ -80,6 +80,9 @@ constexpr int RING = TB_RING;
 #ifndef TB_BUFST
 #define TB_BUFST 1
 #endif
+#ifndef TB_ZERO0
+#define TB_ZERO0 1  // the first sweep from p^0 == 0 in its short form (JacobiOp::apply_from_zero)
+#endif
 #ifndef TB_CHAIN_MINK
 #define TB_CHAIN_MINK 10  // chained chunks (Pipe::run) are instantiated from this sweep count up
 #endif
@@ -383,6 +386,32 @@ template <int C> struct JacobiOp {
     __device__ __forceinline__ void produce(PipeT &, const P &, int, size_t, float *) {}
   };
 
+  // The first sweep from p^0 == 0 (JacobiZeroOp, JacobiDivOp): ((((0 + 0) + 0) + 0) - d) * 0.25 is (0 - d) * 0.25
+  // bit for bit (the three sums of +0 are +0, and +0 - d is what the general rule's last subtraction computes),
+  // so that level costs 2 instructions per column instead of 5 and needs no rows of zeros: 6 of the ~153 VALU
+  // instructions of a 14-sweep step.  The border rules give -(+0) = -0, as the general rule does on rows of +0.
+  static constexpr bool kZeroShortcut = TB_ASM && C == 2 && TB_ZERO0;
+  template <bool XEDGE, bool YCHK>
+  static __device__ __forceinline__ R apply_from_zero(const A &d, int r, int NY, XBorder xb, float zero) {
+    R o;
+    if (YCHK && (r <= 0 || r >= NY - 1)) {  // wave-uniform: -p^0 of the row inward
+#pragma unroll
+      for (int c = 0; c < C; ++c) o.v[c] = neg_opaque(zero);
+      return o;
+    }
+    asm("v_sub_f32 %0, %2, %3\n\t"
+        "v_sub_f32 %1, %2, %4\n\t"
+        "v_mul_f32 %0, 0x3e800000, %0\n\t"
+        "v_mul_f32 %1, 0x3e800000, %1"
+        : "=&v"(o.v[0]), "=&v"(o.v[C > 1 ? 1 : 0])
+        : "v"(zero), "v"(d.v[0]), "v"(d.v[C > 1 ? 1 : 0]));
+    if constexpr (XEDGE) {  // kernel.cu:319-320 on a field of +0
+      o.v[0] = select_neg(o.v[0], zero, xb.lo);
+      o.v[C > 1 ? 1 : 0] = select_neg(o.v[C > 1 ? 1 : 0], zero, xb.hi);
+    }
+    return o;
+  }
+
   template <bool XEDGE, bool YCHK>
   static __device__ __forceinline__ R apply(const R &a, const R &b, const R &n, const A &d, int r,
                                             int x0, int N, int NY, const P &, XBorder xb) {
@@ -443,6 +472,9 @@ template <int C> struct DiffuseOp {
   // (two columns per lane only: the compiler assembles the second 16 bytes of a four-column row through scratch
   // memory — scratch_store 24 bytes, scratch_load 16 at offset 8 — whichever way the vector is written down; the
   // four-column plans are not a default anywhere and keep the pointer stores)
+  static constexpr bool kZeroShortcut = false;
+  template <bool XEDGE, bool YCHK>
+  static __device__ __forceinline__ R apply_from_zero(const A &, int, int, XBorder, float) { return zero(); }
   static constexpr bool kBufStore = TB_BUFST != 0 && C == 2;
   static __device__ __forceinline__ void store_buf(__amdgpu_buffer_rsrc_t rs, unsigned boff, const R &r) {
     buf_store_row2<C>(rs, boff, r);
@@ -724,6 +756,7 @@ template <class Op, int K, bool XEDGE, bool CHAIN = false> struct Pipe {
   R s[K + 1][3];
   A h[K + 3];   // hh(j), j = -2 .. K
   R pf[RING];   // prefetch ring: in phase J, pf[J + i] = level-0 row t + i
+  float zero0;  // +0 the optimiser cannot see through (kZeroShortcut: all there is of a level 0 that is p^0 == 0)
   typename Op::template Feed<XEDGE> feed;  // where the auxiliary rows come from
   Geom g;
   int x0, xc, ya, yb;  // xc: x0 clamped into the domain (address of this lane's loads)
@@ -798,6 +831,7 @@ template <class Op, int K, bool XEDGE, bool CHAIN = false> struct Pipe {
     }
     feed.init(*this, p, t0);
     if constexpr (T > 0) tail.init();
+    asm("v_mov_b32 %0, 0" : "=v"(zero0));
   }
   // the stage after the last level: fin is final row ro; its output is row ro - 1
   template <bool YCHK>
@@ -814,7 +848,7 @@ template <class Op, int K, bool XEDGE, bool CHAIN = false> struct Pipe {
 
   __device__ __forceinline__ void shift_aux() {
 #pragma unroll
-    for (int j = K; j >= 1; --j) hh(j) = hh(j - 3);
+    for (int j = K; j >= 1; --j) hh(j) = hh(j - 3);  // (as v_mov_b64 pairs, half the instructions: no faster, 0.648 vs 0.643 ms)
   }
 
   // LV: levels evaluated (K in the general step; fewer while the pipeline fills, see ramp())
@@ -825,8 +859,15 @@ template <class Op, int K, bool XEDGE, bool CHAIN = false> struct Pipe {
     for (int l = LO; l < LV; ++l) {
       A d = cur;  // a copy of the value (never a select between two rows' addresses)
       if (l > 0) d = hh(l + 1 - J % 3);
-      R o = Op::template apply<XEDGE, YCHK>(s[l][J % 3], s[l][(J + 1) % 3], s[l][(J + 2) % 3], d,
+      R o;
+      if constexpr (!Op::kLoadsField && Op::kZeroShortcut) {
+        if (l == 0) o = Op::template apply_from_zero<XEDGE, YCHK>(d, t - 1, g.ny, xb, zero0);
+        else o = Op::template apply<XEDGE, YCHK>(s[l][J % 3], s[l][(J + 1) % 3], s[l][(J + 2) % 3], d,
+                                                 t - l - 1, x0, g.n, g.ny, p, xb);
+      } else {
+        o = Op::template apply<XEDGE, YCHK>(s[l][J % 3], s[l][(J + 1) % 3], s[l][(J + 2) % 3], d,
                                             t - l - 1, x0, g.n, g.ny, p, xb);
+      }
       if (l + 1 < K) s[l + 1][(J + 2) % 3] = o; else fin = o;
     }
     return fin;
